@@ -1,0 +1,165 @@
+"""
+Generate the golden fixtures under tests/golden/ (run in the BUILD container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Sources of truth (none of them travels to the GPU box; only the .npz outputs do):
+
+1. ``kat_sklearn_matern32.npz`` -- the reference's own known-answer fixture,
+   tests/test_localexperts.py:22-49 replayed verbatim with scikit-learn
+   (the oracle the reference's test_gpflow_gpr compares GPflowGPRModel against).
+2. ``ref_purepython_matern32_N*.npz`` -- outputs of the REFERENCE's NumPy functions
+   SGPkernel / SMLII_mod / GPR (GPSat/models/pure_python_gpr.py:378-553), imported
+   from /root/reference.  Unrelated heavy imports of the package (tensorflow, tables,
+   numba, pyproj, deprecated) are absent in this container and are satisfied by inert
+   placeholder modules; only the three pure NumPy/SciPy functions are executed.
+3. ``kat_notebook_rbf.npz`` -- inputs regenerated from the seeds printed in
+   docs/notebooks/gp_regression.ipynb (cell 3) together with the values that notebook
+   prints (LML 16.6180 -> 21.4700, lengthscale 1.5648, kernel_variance 0.5168).
+4. ``transforms.npz`` -- softplus / sigmoid tables on the grids of tests/test_utils.py:962-1023.
+
+Fixtures are DATA (inputs + expected outputs), never reference source text.
+"""
+import os
+import sys
+import types
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def kat_sklearn():
+    from sklearn.gaussian_process.kernels import Matern
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    np.random.seed(23435)
+    kernel = Matern(length_scale=0.8, nu=3 / 2)
+    gp = GaussianProcessRegressor(kernel)
+    x = np.linspace(0, 10, 100)[:, None]
+    f = gp.sample_y(x, random_state=0)
+    N = 50
+    eps = 1e-2
+    indices = np.arange(100)
+    np.random.shuffle(indices)
+    x_train = x[indices[:N]]
+    y_train = f[indices[:N]] + eps * np.random.randn(N, 1)
+    gp.alpha = eps ** 2
+    gp.fit(x_train, y_train)
+    ls = gp.kernel_.length_scale
+    ml = gp.log_marginal_likelihood()
+    test_index = np.random.randint(0, 99)
+    x_test = x[[test_index]]
+    pred_mean, pred_std = gp.predict(x_test, return_std=True)
+    np.savez(os.path.join(HERE, "kat_sklearn_matern32.npz"),
+             x_train=x_train[:, 0], y_train=y_train[:, 0], eps=eps, ls=ls, ml=ml,
+             test_index=test_index, x_test=x_test[0, 0],
+             pred_mean=np.ravel(pred_mean)[0], pred_std=np.ravel(pred_std)[0])
+    print("sklearn KAT: ls", ls, "ml", ml, "x*", x_test[0, 0], "mean", pred_mean, "std", pred_std)
+
+
+class _Inert(types.ModuleType):
+    """Placeholder for absent third-party modules: attribute access returns an inert
+    object that is callable / decorator-transparent / subscriptable / iterable-as-empty."""
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _InertObj()
+
+
+class _InertObj:
+    def __call__(self, *a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return _InertObj()
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _InertObj()
+
+    def __getitem__(self, k):
+        return _InertObj()
+
+    def __iter__(self):
+        return iter(())
+
+
+def ref_purepython():
+    for name in ["tensorflow", "tensorflow.python", "tensorflow.python.client", "tables", "numba",
+                 "pyproj", "deprecated"]:
+        if name not in sys.modules:
+            sys.modules[name] = _Inert(name)
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    from GPSat.models.pure_python_gpr import SGPkernel, SMLII_mod, GPR
+    for N in (16, 128, 500):
+        rng = np.random.default_rng(1000 + N)
+        D = 3
+        x = np.column_stack([rng.uniform(-6, 6, N), rng.uniform(-6, 6, N), rng.uniform(-4, 4, N)])
+        ell = np.array([3.0, 4.5, 5.0])
+        sf2, sn2 = 0.7, 0.05
+        K = SGPkernel(x, ell=ell, sigma=sf2) + sn2 * np.eye(N)
+        y = np.linalg.cholesky(K) @ rng.standard_normal(N)
+        P = 24
+        xs = np.column_stack([rng.uniform(-4, 4, P), rng.uniform(-4, 4, P), np.zeros(P)])
+        thetas = np.array([[3.0, 4.5, 5.0, 0.7, 0.05],
+                           [1.0, 1.0, 1.0, 1.0, 1.0],
+                           [2.0, 7.0, 3.5, 0.3, 0.01]])
+        nll = np.array([float(np.squeeze(SMLII_mod(hypers=th, x=x, y=y, grad=False))) for th in thetas])
+        # gradient goldens: central differences of the reference NLL (fp64), w.r.t. theta
+        grads = np.zeros_like(thetas)
+        for i, th in enumerate(thetas):
+            for j in range(5):
+                h = 1e-5 * max(1.0, abs(th[j]))
+                tp, tm = th.copy(), th.copy()
+                tp[j] += h
+                tm[j] -= h
+                grads[i, j] = (float(np.squeeze(SMLII_mod(hypers=tp, x=x, y=y, grad=False))) -
+                               float(np.squeeze(SMLII_mod(hypers=tm, x=x, y=y, grad=False)))) / (2 * h)
+        means, stds = [], []
+        for th in thetas:
+            m, s = GPR(x, y[:, None], xs, th[:3], th[3], th[4], mean=0)
+            means.append(np.ravel(m))
+            stds.append(np.ravel(s))
+        Kxx = SGPkernel(x[:8], ell=ell, sigma=sf2)
+        np.savez(os.path.join(HERE, f"ref_purepython_matern32_N{N}.npz"),
+                 x=x, y=y, xs=xs, thetas=thetas, nll=nll, grads_fd=grads,
+                 pred_mean=np.array(means), pred_std=np.array(stds), K8=Kxx)
+        print(f"ref pure-python N={N}: nll {nll}")
+
+
+def kat_notebook_rbf():
+    np.random.seed(0)
+    N, L, noise_std = 30, 5, 0.05
+    X_grid = np.linspace(-L, L, 100)
+    X = np.random.uniform(-L, L, (N,))
+    epsilon = noise_std * np.random.randn(N)
+    y = np.cos(X) + epsilon
+    np.savez(os.path.join(HERE, "kat_notebook_rbf.npz"), X=X, y=y, X_grid=X_grid,
+             f_truth=np.cos(X_grid),
+             # printed by docs/notebooks/gp_regression.ipynb (sklearnGPRModel: amplitude = sqrt(printed kv),
+             # GPSat/models/sklearn_models.py:96)
+             lml_init=16.6180, kv_printed_init=1.5, lik_var=0.0025, ls_init=1.0,
+             mse_init=0.0026, mll_init=1.4578,
+             ls_opt=1.5648, kv_printed_opt=0.5168, lml_opt=21.4700, mse_opt=0.0037, mll_opt=1.8717)
+    print("notebook KAT data written")
+
+
+def transforms():
+    x1 = np.linspace(-100, 100, 1000)
+    x2 = np.linspace(-10, 10, 1000)
+    # closed forms in extended precision as the independent check of the fp64 restatement
+    xl = x1.astype(np.longdouble)
+    sp = np.where(xl > 0, xl + np.log1p(np.exp(-xl)), np.log1p(np.exp(xl))).astype(np.float64)
+    x2l = x2.astype(np.longdouble)
+    sg = (1 / (1 + np.exp(-x2l))).astype(np.float64)
+    np.savez(os.path.join(HERE, "transforms.npz"), x_softplus=x1, softplus=sp, x_sigmoid=x2, sigmoid=sg)
+    print("transform tables written")
+
+
+if __name__ == "__main__":
+    kat_sklearn()
+    kat_notebook_rbf()
+    transforms()
+    ref_purepython()

@@ -1,0 +1,110 @@
+"""Pin the CPU oracle (oracle/gp_oracle.py) against the reference's own known answers.
+
+* tests/test_localexperts.py:203-227 (reference): lengthscale, LML, f*, f*_var to 1e-6
+* GPSat/models/pure_python_gpr.py SGPkernel/SMLII_mod/GPR outputs (tests/golden/ref_purepython_*.npz)
+* docs/notebooks/gp_regression.ipynb printed values
+* tests/test_utils.py:962-1023 transform tolerances (1e-14 / 1e-12)
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as go
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_kat_sklearn_matern32(golden_dir):
+    """Exactly the assertions of the reference's test_gpflow_gpr (tol 1e-6)."""
+    g = _load(golden_dir, "kat_sklearn_matern32.npz")
+    m = go.OracleGPR(coords=g["x_train"], obs=g["y_train"], obs_mean=None, kernel="Matern32")
+    m.set_parameters(likelihood_variance=float(g["eps"]) ** 2)
+    m.set_parameter_constraints({"lengthscales": {"low": 1e-10, "high": 5.0}})
+    ok = m.optimise_parameters(fixed_params=["likelihood_variance", "kernel_variance"])
+    out = m.predict(np.array([[float(g["x_test"])]]))
+    tol = 1e-6
+    assert ok
+    assert abs(m.get_parameters()["lengthscales"][0] - float(g["ls"])) < tol
+    assert abs(-m.get_objective_function_value() - float(g["ml"])) < tol
+    assert abs(out["f*"][0] - float(g["pred_mean"])) < tol
+    assert abs(out["f*_var"][0] - float(g["pred_std"]) ** 2) < tol
+    assert abs(out["y_var"][0] - (float(g["pred_std"]) ** 2 + 1e-4)) < tol
+
+
+@pytest.mark.parametrize("N", [16, 128, 500])
+def test_reference_numpy_functions(golden_dir, N):
+    g = _load(golden_dir, f"ref_purepython_matern32_N{N}.npz")
+    x, y, xs = g["x"], g["y"], g["xs"]
+    K8 = go.kernel_matrix(2, x[:8], x[:8], np.array([3.0, 4.5, 5.0]), 0.7)
+    np.testing.assert_allclose(K8, g["K8"], rtol=0, atol=1e-13)
+    for i, th in enumerate(g["thetas"]):
+        nll, grad = go.nll_and_grad(2, x, y, th)
+        assert abs(nll - g["nll"][i]) < 1e-8 * max(1.0, abs(g["nll"][i]))
+        # gradient oracle = central differences of the REFERENCE NLL
+        np.testing.assert_allclose(grad, g["grads_fd"][i], rtol=2e-5, atol=2e-5)
+        f, fv, yv = go.predict(2, x, y, xs, th)
+        np.testing.assert_allclose(f, g["pred_mean"][i], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(np.sqrt(fv), g["pred_std"][i], rtol=0, atol=1e-8)
+
+
+def test_notebook_rbf_kat(golden_dir):
+    g = _load(golden_dir, "kat_notebook_rbf.npz")
+    X, y = g["X"][:, None], g["y"]
+    # printed kernel_variance is amplitude**2 of sklearn's ConstantKernel (sklearn_models.py:96)
+    th0 = np.array([1.0, np.sqrt(1.5), 0.0025])
+    nll0, _ = go.nll_and_grad(0, X, y, th0)
+    assert abs(-nll0 - float(g["lml_init"])) < 5e-4
+    f, fv, _ = go.predict(0, X, y, g["X_grid"][:, None], th0)
+    assert abs(np.mean((g["f_truth"] - f) ** 2) - float(g["mse_init"])) < 1e-4
+    # optimise lengthscale + kernel variance with likelihood variance fixed
+    m = go.OracleGPR(coords=X, obs=y, kernel="RBF", kernel_kwargs={"variance": np.sqrt(1.5)},
+                     noise_variance=0.0025)
+    assert m.optimise_parameters(fixed_params=["likelihood_variance"])
+    p = m.get_parameters()
+    assert abs(p["lengthscales"][0] - float(g["ls_opt"])) < 2e-4
+    assert abs(p["kernel_variance"] ** 2 - float(g["kv_printed_opt"])) < 2e-4
+    assert abs(-m.get_objective_function_value() - float(g["lml_opt"])) < 5e-4
+
+
+def test_transforms(golden_dir):
+    g = _load(golden_dir, "transforms.npz")
+    x = g["x_softplus"]
+    y = go.softplus(x)
+    np.testing.assert_array_almost_equal(y, g["softplus"], decimal=14)
+    np.testing.assert_array_almost_equal(go.softplus(x, shift=10.0), y + 10.0, decimal=14)
+    np.testing.assert_array_almost_equal(go.inverse_softplus(y), x, decimal=14)
+    assert go.inverse_softplus(np.array(-1.0)) == -np.inf
+    x2 = g["x_sigmoid"]
+    s = go.sigmoid(x2)
+    np.testing.assert_array_almost_equal(s, g["sigmoid"], decimal=14)
+    np.testing.assert_array_almost_equal(go.inverse_sigmoid(s), x2, decimal=12)
+    s2 = go.sigmoid(x2, -1, 1)
+    np.testing.assert_array_almost_equal(s2, g["sigmoid"] * 2 - 1, decimal=14)
+    np.testing.assert_array_almost_equal(go.inverse_sigmoid(s2, -1, 1), x2, decimal=12)
+    assert go.inverse_sigmoid(np.array(-1.5), -1.0, 2.0) == -np.inf
+    assert go.inverse_sigmoid(np.array(2.0), -1.0, 2.0) == np.inf
+
+
+def test_gradient_chain_all_kernels():
+    """dNLL/du by the analytic chain equals central differences for every kernel / transform."""
+    rng = np.random.default_rng(5)
+    N, D = 40, 3
+    X = rng.uniform(-3, 3, (N, D))
+    y = rng.standard_normal(N)
+    lo = np.array([1e-8, 1e-8, np.nan, np.nan, np.nan])
+    hi = np.array([12.0, 9.0, np.nan, np.nan, np.nan])
+    shift = np.array([0, 0, 0, 0, go.LIK_VAR_LOWER])
+    u = rng.standard_normal(D + 2) * 0.5
+    for kid in range(4):
+        def f(u_):
+            th = go.theta_from_u(u_, lo, hi, shift)
+            return go.nll_and_grad(kid, X, y, th, want_grad=False)[0]
+        th = go.theta_from_u(u, lo, hi, shift)
+        _, g = go.nll_and_grad(kid, X, y, th)
+        gu = g * go.dtheta_du(th, lo, hi, shift)
+        fd = np.array([(f(u + 1e-6 * e) - f(u - 1e-6 * e)) / 2e-6 for e in np.eye(D + 2)])
+        np.testing.assert_allclose(gu, fd, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(go.u_from_theta(go.theta_from_u(u, lo, hi, shift), lo, hi, shift), u, atol=1e-9)
