@@ -1,0 +1,82 @@
+"""ctypes binding of libgpsat_hip.so (C ABI declared in include/gpsat_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a symbol is
+absent, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgpsat_hip.so")
+
+# constants mirrored from include/gpsat_hip.h
+ABI_VERSION = 1
+F32, F64 = 0, 1
+KERNEL_IDS = {"RBF": 0, "SquaredExponential": 0, "Matern12": 1, "Exponential": 1, "Matern32": 2, "Matern52": 3}
+OPT_NONE, OPT_LBFGS, OPT_ADAM = 0, 1, 2
+OPT_IDS = {"none": OPT_NONE, None: OPT_NONE, "lbfgs": OPT_LBFGS, "L-BFGS-B": OPT_LBFGS, "adam": OPT_ADAM}
+MEM_HOST, MEM_DEVICE = 0, 1
+STATUS = {0: "converged", 1: "max_iter", 2: "not_pd", 3: "nan", 4: "skipped", 5: "not_optimised"}
+
+EXPORTS = ["gpsat_version", "gpsat_last_error", "gpsat_device_count", "gpsat_create", "gpsat_device_name",
+           "gpsat_destroy", "gpsat_fit_predict_batch", "gpsat_last_timing"]
+
+
+class GpsatOpts(C.Structure):
+    _fields_ = [("workgroups_per_cu", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class GpsatBatch(C.Structure):
+    _fields_ = [
+        ("T", C.c_int32), ("D", C.c_int32), ("dtype", C.c_int32), ("kernel", C.c_int32),
+        ("memory", C.c_int32), ("optimiser", C.c_int32), ("max_iter", C.c_int32), ("max_ls", C.c_int32),
+        ("ftol", C.c_double), ("gtol", C.c_double), ("adam_lr", C.c_double),
+        ("obs_off", C.c_void_p), ("pred_off", C.c_void_p), ("theta0", C.c_void_p), ("lo", C.c_void_p),
+        ("hi", C.c_void_p), ("trainable", C.c_void_p),
+        ("X", C.c_void_p), ("y", C.c_void_p), ("Xs", C.c_void_p),
+        ("theta", C.c_void_p), ("nll", C.c_void_p), ("grad", C.c_void_p), ("status", C.c_void_p),
+        ("n_eval", C.c_void_p), ("f_mean", C.c_void_p), ("f_var", C.c_void_p), ("y_var", C.c_void_p),
+    ]
+
+
+class LibraryMissing(ImportError):
+    pass
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C gpsat_amd/csrc` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise LibraryMissing(f"{LIB_PATH} does not export {name}")
+    lib.gpsat_version.restype = C.c_int
+    lib.gpsat_last_error.restype = C.c_char_p
+    lib.gpsat_device_count.restype = C.c_int
+    lib.gpsat_create.restype = C.c_int
+    lib.gpsat_create.argtypes = [C.c_int, C.POINTER(GpsatOpts), C.POINTER(C.c_void_p)]
+    lib.gpsat_device_name.restype = C.c_int
+    lib.gpsat_device_name.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    lib.gpsat_destroy.restype = C.c_int
+    lib.gpsat_destroy.argtypes = [C.c_void_p]
+    lib.gpsat_fit_predict_batch.restype = C.c_int
+    lib.gpsat_fit_predict_batch.argtypes = [C.c_void_p, C.POINTER(GpsatBatch)]
+    lib.gpsat_last_timing.restype = C.c_int
+    lib.gpsat_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    if lib.gpsat_version() != ABI_VERSION:
+        raise LibraryMissing(f"ABI version mismatch: library {lib.gpsat_version()} != binding {ABI_VERSION}")
+    return lib
+
+
+_lib = None
+
+
+def get_lib():
+    global _lib
+    if _lib is None:
+        _lib = load()
+    return _lib

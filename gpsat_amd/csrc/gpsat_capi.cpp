@@ -1,0 +1,262 @@
+// gpsat_capi.cpp -- C ABI of libgpsat_hip.so (see include/gpsat_hip.h for the contract and the
+// reference interfaces each entry point replaces).  Host-side responsibilities only: argument
+// validation, device buffers owned by the handle, cost-sorted tile order, launch, copy-back.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "gpsat_hip.h"
+#include "gpsat_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(e_ == hipErrorOutOfMemory ? GPSAT_ENOMEM : GPSAT_EHIP,                    \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return GPSAT_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(GPSAT_ENOMEM, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+        }
+        cap = want;
+        return GPSAT_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct gpsat_handle {
+    int device = 0;
+    int num_cu = 0;
+    int wg_per_cu = 2;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    char name[256] = {0};
+    double last_kernel_ms = 0.0, last_total_ms = 0.0;
+    // device buffers (grown lazily, owned by the handle)
+    DevBuf meta_i64, meta_f64, meta_misc, out_f64, out_i32, bulk_in, bulk_out, ws;
+};
+
+extern "C" {
+
+int gpsat_version(void) { return GPSAT_ABI_VERSION; }
+
+const char* gpsat_last_error(void) { return g_err.c_str(); }
+
+int gpsat_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int gpsat_create(int device_id, const gpsat_opts* opts, gpsat_handle** out) {
+    if (!out) return fail(GPSAT_EINVAL, "gpsat_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(GPSAT_ENODEV, "gpsat_create: no HIP device visible");
+    if (device_id < 0 || device_id >= n) return fail(GPSAT_EINVAL, "gpsat_create: device_id out of range");
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    gpsat_handle* h = new (std::nothrow) gpsat_handle();
+    if (!h) return fail(GPSAT_ENOMEM, "gpsat_create: host allocation failed");
+    h->device = device_id;
+    h->num_cu = prop.multiProcessorCount;
+    std::snprintf(h->name, sizeof(h->name), "%s (%s)", prop.name, prop.gcnArchName);
+    if (opts && opts->workgroups_per_cu > 0) h->wg_per_cu = std::min(opts->workgroups_per_cu, 8);
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail(GPSAT_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    for (int i = 0; i < 4; ++i) {
+        e = hipEventCreate(&h->ev[i]);
+        if (e != hipSuccess) { gpsat_destroy(h); return fail(GPSAT_EHIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
+    }
+    *out = h;
+    return GPSAT_OK;
+}
+
+int gpsat_device_name(gpsat_handle* h, char* buf, int buflen) {
+    if (!h || !buf || buflen <= 0) return fail(GPSAT_EINVAL, "gpsat_device_name: bad argument");
+    std::snprintf(buf, (size_t)buflen, "%s", h->name);
+    return GPSAT_OK;
+}
+
+int gpsat_destroy(gpsat_handle* h) {
+    if (!h) return GPSAT_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->meta_i64.release(); h->meta_f64.release(); h->meta_misc.release(); h->out_f64.release();
+    h->out_i32.release(); h->bulk_in.release(); h->bulk_out.release(); h->ws.release();
+    for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return GPSAT_OK;
+}
+
+int gpsat_last_timing(gpsat_handle* h, double* kernel_ms, double* total_ms) {
+    if (!h) return fail(GPSAT_EINVAL, "gpsat_last_timing: handle is NULL");
+    if (kernel_ms) *kernel_ms = h->last_kernel_ms;
+    if (total_ms) *total_ms = h->last_total_ms;
+    return GPSAT_OK;
+}
+
+int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
+    if (!h || !b) return fail(GPSAT_EINVAL, "gpsat_fit_predict_batch: NULL handle or batch");
+    if (b->T < 0) return fail(GPSAT_EINVAL, "T < 0");
+    if (b->T == 0) return GPSAT_OK;
+    if (b->D < 1 || b->D > 3) return fail(GPSAT_EINVAL, "D must be 1..3 in this build");
+    if (b->dtype != GPSAT_F32) return fail(GPSAT_EINVAL, "dtype: only GPSAT_F32 is built");
+    if (b->kernel < 0 || b->kernel > 3) return fail(GPSAT_EINVAL, "unknown kernel id");
+    if (b->optimiser < 0 || b->optimiser > 2) return fail(GPSAT_EINVAL, "unknown optimiser id");
+    if (b->memory != GPSAT_MEM_HOST && b->memory != GPSAT_MEM_DEVICE) return fail(GPSAT_EINVAL, "bad memory flag");
+    if (!b->obs_off || !b->pred_off || !b->theta0 || !b->lo || !b->hi || !b->trainable)
+        return fail(GPSAT_EINVAL, "metadata pointer is NULL");
+    if (!b->theta || !b->nll || !b->status || !b->n_eval) return fail(GPSAT_EINVAL, "output pointer is NULL");
+    const int T = b->T, D = b->D, H = D + 2;
+    // ---- validate CSR offsets, find the largest tile
+    long long maxN = 0;
+    if (b->obs_off[0] != 0 || b->pred_off[0] != 0) return fail(GPSAT_EINVAL, "offsets must start at 0");
+    for (int t = 0; t < T; ++t) {
+        const long long n = b->obs_off[t + 1] - b->obs_off[t], p = b->pred_off[t + 1] - b->pred_off[t];
+        if (n < 0 || p < 0) return fail(GPSAT_EINVAL, "offsets must be non-decreasing");
+        maxN = std::max(maxN, n);
+    }
+    const long long sumN = b->obs_off[T], sumP = b->pred_off[T];
+    if (maxN > 4096) return fail(GPSAT_EINVAL, "tile with more than 4096 observations is not supported by this build");
+    if (sumN > 0 && (!b->X || !b->y)) return fail(GPSAT_EINVAL, "X / y is NULL");
+    if (sumP > 0 && (!b->Xs || !b->f_mean || !b->f_var || !b->y_var)) return fail(GPSAT_EINVAL, "prediction pointer is NULL");
+    for (int t = 0; t < T; ++t)
+        for (int i = 0; i < H; ++i) {
+            const double v = b->theta0[(size_t)t * H + i];
+            if (!(v > 0.0) || !std::isfinite(v)) return fail(GPSAT_EINVAL, "theta0 must be finite and positive");
+        }
+    const int NBmax = std::max(1, (int)((maxN + 31) / 32));
+
+    HIP_TRY(hipSetDevice(h->device));
+    // ---- tile order: largest cost first (N^3), stable so equal tiles keep the reference order
+    std::vector<int> order(T);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int c) {
+        return (b->obs_off[a + 1] - b->obs_off[a]) > (b->obs_off[c + 1] - b->obs_off[c]);
+    });
+
+    // ---- device buffers
+    const size_t n_i64 = 2 * (size_t)(T + 1);
+    const size_t n_f64 = 3 * (size_t)T * H;
+    int rc;
+    if ((rc = h->meta_i64.reserve(n_i64 * sizeof(long long)))) return rc;
+    if ((rc = h->meta_f64.reserve(n_f64 * sizeof(double)))) return rc;
+    if ((rc = h->meta_misc.reserve((size_t)T * sizeof(int) + 64 + 16))) return rc;
+    if ((rc = h->out_f64.reserve(((size_t)T * H * 2 + (size_t)T) * sizeof(double)))) return rc;
+    if ((rc = h->out_i32.reserve((size_t)T * 2 * sizeof(int)))) return rc;
+    const size_t wsf = gpsat::workspace_floats_per_wg(NBmax);
+    int grid = std::min(T, h->num_cu * h->wg_per_cu);
+    const size_t smem = gpsat::shared_bytes(D, NBmax);
+    if (smem > 160 * 1024) return fail(GPSAT_EINVAL, "tile too large for LDS");
+    if (smem > 80 * 1024) grid = std::min(grid, h->num_cu);
+    if ((rc = h->ws.reserve((size_t)grid * wsf * sizeof(float)))) return rc;
+
+    const float *dX = nullptr, *dy = nullptr, *dXs = nullptr;
+    float *dfm = nullptr, *dfv = nullptr, *dyv = nullptr;
+    HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+    if (b->memory == GPSAT_MEM_HOST) {
+        const size_t in_f = (size_t)sumN * D + (size_t)sumN + (size_t)sumP * D;
+        if ((rc = h->bulk_in.reserve(std::max<size_t>(in_f, 1) * sizeof(float)))) return rc;
+        if ((rc = h->bulk_out.reserve(std::max<size_t>((size_t)sumP * 3, 1) * sizeof(float)))) return rc;
+        float* base = static_cast<float*>(h->bulk_in.p);
+        if (sumN > 0) {
+            HIP_TRY(hipMemcpyAsync(base, b->X, (size_t)sumN * D * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(base + (size_t)sumN * D, b->y, (size_t)sumN * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        }
+        if (sumP > 0)
+            HIP_TRY(hipMemcpyAsync(base + (size_t)sumN * (D + 1), b->Xs, (size_t)sumP * D * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        dX = base; dy = base + (size_t)sumN * D; dXs = base + (size_t)sumN * (D + 1);
+        dfm = static_cast<float*>(h->bulk_out.p); dfv = dfm + sumP; dyv = dfv + sumP;
+    } else {
+        dX = static_cast<const float*>(b->X); dy = static_cast<const float*>(b->y); dXs = static_cast<const float*>(b->Xs);
+        dfm = static_cast<float*>(b->f_mean); dfv = static_cast<float*>(b->f_var); dyv = static_cast<float*>(b->y_var);
+    }
+    long long* d_i64 = static_cast<long long*>(h->meta_i64.p);
+    HIP_TRY(hipMemcpyAsync(d_i64, b->obs_off, (size_t)(T + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_i64 + (T + 1), b->pred_off, (size_t)(T + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    double* d_f64 = static_cast<double*>(h->meta_f64.p);
+    HIP_TRY(hipMemcpyAsync(d_f64, b->theta0, (size_t)T * H * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_f64 + (size_t)T * H, b->lo, (size_t)T * H * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_f64 + 2 * (size_t)T * H, b->hi, (size_t)T * H * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    unsigned char* d_misc = static_cast<unsigned char*>(h->meta_misc.p);
+    int* d_queue = reinterpret_cast<int*>(d_misc);            // 16 bytes reserved
+    unsigned char* d_train = d_misc + 16;                     // 64 bytes reserved
+    int* d_order = reinterpret_cast<int*>(d_misc + 16 + 64);
+    HIP_TRY(hipMemsetAsync(d_queue, 0, 16, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_train, b->trainable, (size_t)H, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_order, order.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, h->stream));
+
+    gpsat::KernelArgs a;
+    a.T = T; a.kernel = b->kernel; a.optimiser = b->optimiser; a.max_iter = b->max_iter;
+    a.max_ls = b->max_ls > 0 ? b->max_ls : 20;
+    a.NBmax = NBmax;
+    a.ftol = b->ftol > 0 ? b->ftol : 1e-7;
+    a.gtol = b->gtol > 0 ? b->gtol : 1e-5;
+    a.adam_lr = b->adam_lr > 0 ? b->adam_lr : 0.1;
+    a.obs_off = d_i64; a.pred_off = d_i64 + (T + 1);
+    a.theta0 = d_f64; a.lo = d_f64 + (size_t)T * H; a.hi = d_f64 + 2 * (size_t)T * H;
+    a.trainable = d_train;
+    a.X = dX; a.y = dy; a.Xs = dXs;
+    double* d_out = static_cast<double*>(h->out_f64.p);
+    a.theta = d_out; a.nll = d_out + (size_t)T * H;
+    a.grad = b->grad ? d_out + (size_t)T * H + T : nullptr;
+    int* d_oi = static_cast<int*>(h->out_i32.p);
+    a.status = d_oi; a.n_eval = d_oi + T;
+    a.f_mean = dfm; a.f_var = dfv; a.y_var = dyv;
+    a.order = d_order; a.queue = d_queue;
+    a.ws = static_cast<float*>(h->ws.p); a.ws_stride = wsf;
+
+    HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+    HIP_TRY(gpsat::launch_tiles(D, a, grid, smem, h->stream));
+    HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+
+    HIP_TRY(hipMemcpyAsync(b->theta, a.theta, (size_t)T * H * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(b->nll, a.nll, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (b->grad) HIP_TRY(hipMemcpyAsync(b->grad, a.grad, (size_t)T * H * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(b->status, a.status, (size_t)T * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(b->n_eval, a.n_eval, (size_t)T * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (b->memory == GPSAT_MEM_HOST && sumP > 0) {
+        HIP_TRY(hipMemcpyAsync(b->f_mean, dfm, (size_t)sumP * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(b->f_var, dfv, (size_t)sumP * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(b->y_var, dyv, (size_t)sumP * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float km = 0.f, tm = 0.f;
+    HIP_TRY(hipEventElapsedTime(&km, h->ev[1], h->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&tm, h->ev[0], h->ev[3]));
+    h->last_kernel_ms = km;
+    h->last_total_ms = tm;
+    return GPSAT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,41 @@
+// gpsat_kernels.h -- internal interface between the C ABI (gpsat_capi.cpp) and the gfx950 kernels.
+#ifndef GPSAT_KERNELS_H
+#define GPSAT_KERNELS_H
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace gpsat {
+
+// All pointers are DEVICE pointers.
+struct KernelArgs {
+    int T, kernel, optimiser, max_iter, max_ls, NBmax;
+    double ftol, gtol, adam_lr;
+    const long long* obs_off;     // [T+1]
+    const long long* pred_off;    // [T+1]
+    const double* theta0;         // [T*H]
+    const double* lo;             // [T*H]
+    const double* hi;             // [T*H]
+    const unsigned char* trainable;  // [H]
+    const float* X;               // [sumN*D]
+    const float* y;               // [sumN]
+    const float* Xs;              // [sumP*D]
+    double* theta;                // [T*H]
+    double* nll;                  // [T]
+    double* grad;                 // [T*H] or nullptr
+    int* status;                  // [T]
+    int* n_eval;                  // [T]
+    float* f_mean;                // [sumP]
+    float* f_var;
+    float* y_var;
+    const int* order;             // [T] tile processing order (largest first)
+    int* queue;                   // work-queue head (zeroed before launch)
+    float* ws;                    // per-workgroup workspace
+    size_t ws_stride;             // floats per workgroup
+};
+
+size_t shared_bytes(int D, int NBmax);
+size_t workspace_floats_per_wg(int NBmax);
+hipError_t launch_tiles(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream);
+
+}  // namespace gpsat
+#endif

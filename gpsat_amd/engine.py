@@ -1,0 +1,158 @@
+"""Batched local-expert GP engine: thin host wrapper over the C ABI (include/gpsat_hip.h).
+
+``Engine.fit_predict_batch`` is the packed-ragged counterpart of the per-tile body of
+LocalExpertOI.run (GPSat/local_experts.py:1043-1159): all tiles of a wave are fitted and
+predicted by ONE call / one kernel launch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+
+
+class GpsatError(RuntimeError):
+    pass
+
+
+@dataclass
+class BatchResult:
+    theta: np.ndarray      # [T, H] learned parameters (l_1..l_D, kernel_variance, likelihood_variance)
+    nll: np.ndarray        # [T] objective = negative log marginal likelihood
+    status: np.ndarray     # [T] see _lib.STATUS
+    n_eval: np.ndarray     # [T] objective+gradient evaluations used by the optimiser
+    f_mean: object         # [sum P] numpy (host mode) or torch tensor (device mode)
+    f_var: object
+    y_var: object
+    grad: np.ndarray | None = None   # [T, H] dNLL/dtheta at theta (when requested)
+    kernel_ms: float = 0.0
+    total_ms: float = 0.0
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Engine:
+    """One engine per GPU (one process per GPU in multi-GPU runs)."""
+
+    def __init__(self, device_id: int = 0, workgroups_per_cu: int = 0):
+        self._lib = L.get_lib()
+        opts = L.GpsatOpts()
+        opts.workgroups_per_cu = int(workgroups_per_cu)
+        h = C.c_void_p()
+        rc = self._lib.gpsat_create(int(device_id), C.byref(opts), C.byref(h))
+        if rc != 0:
+            raise GpsatError(f"gpsat_create failed ({rc}): {self._lib.gpsat_last_error().decode()}")
+        self._h = h
+        buf = C.create_string_buffer(256)
+        self._lib.gpsat_device_name(self._h, buf, 256)
+        self.device_name = buf.value.decode()
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gpsat_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def fit_predict_batch(self, *, D, obs_off, X, y, pred_off, Xs, theta0, lo=None, hi=None,
+                          trainable=None, kernel="Matern32", optimiser="lbfgs", max_iter=10_000,
+                          max_ls=20, ftol=0.0, gtol=0.0, adam_lr=0.0, want_grad=False,
+                          out=None) -> BatchResult:
+        """
+        X [sumN, D], y [sumN], Xs [sumP, D]: float32 numpy arrays (host mode) or torch.cuda float32
+        tensors (device mode; outputs are then torch tensors, optionally preallocated via ``out``=
+        (f_mean, f_var, y_var)).  Offsets / theta0 / bounds are always host numpy.
+        """
+        obs_off = np.ascontiguousarray(obs_off, dtype=np.int64)
+        pred_off = np.ascontiguousarray(pred_off, dtype=np.int64)
+        T = len(obs_off) - 1
+        H = D + 2
+        assert len(pred_off) == T + 1
+        theta0 = np.ascontiguousarray(np.broadcast_to(np.asarray(theta0, dtype=np.float64), (T, H)))
+        lo = np.full((T, H), np.nan) if lo is None else \
+            np.ascontiguousarray(np.broadcast_to(np.asarray(lo, dtype=np.float64), (T, H)))
+        hi = np.full((T, H), np.nan) if hi is None else \
+            np.ascontiguousarray(np.broadcast_to(np.asarray(hi, dtype=np.float64), (T, H)))
+        trainable = np.ones(H, dtype=np.uint8) if trainable is None else \
+            np.ascontiguousarray(np.asarray(trainable).astype(bool).astype(np.uint8))
+        assert trainable.shape == (H,)
+        sumN, sumP = int(obs_off[-1]), int(pred_off[-1])
+
+        device_mode = not isinstance(X, np.ndarray)
+        if device_mode:
+            import torch
+            for tname, t_ in (("X", X), ("y", y), ("Xs", Xs)):
+                if not (isinstance(t_, torch.Tensor) and t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous()):
+                    raise GpsatError(f"{tname}: device mode needs contiguous float32 CUDA tensors")
+            if X.device.index != self.device_id:
+                raise GpsatError(f"tensors live on cuda:{X.device.index}, engine on device {self.device_id}")
+            assert X.numel() == sumN * D and y.numel() == sumN and Xs.numel() == sumP * D
+            if out is None:
+                fm = torch.empty(max(sumP, 1), dtype=torch.float32, device=X.device)
+                fv = torch.empty_like(fm)
+                yv = torch.empty_like(fm)
+            else:
+                fm, fv, yv = out
+            torch.cuda.current_stream(X.device).synchronize()   # inputs must be complete before our stream reads them
+            pX, py, pXs = X.data_ptr(), y.data_ptr(), Xs.data_ptr()
+            pfm, pfv, pyv = fm.data_ptr(), fv.data_ptr(), yv.data_ptr()
+        else:
+            X = np.ascontiguousarray(X, dtype=np.float32).reshape(sumN, D)
+            y = np.ascontiguousarray(y, dtype=np.float32).reshape(sumN)
+            Xs = np.ascontiguousarray(Xs, dtype=np.float32).reshape(sumP, D)
+            fm = np.empty(sumP, dtype=np.float32)
+            fv = np.empty(sumP, dtype=np.float32)
+            yv = np.empty(sumP, dtype=np.float32)
+            pX, py, pXs = _ptr(X), _ptr(y), _ptr(Xs)
+            pfm, pfv, pyv = _ptr(fm), _ptr(fv), _ptr(yv)
+
+        theta = np.empty((T, H), dtype=np.float64)
+        nll = np.empty(T, dtype=np.float64)
+        grad = np.empty((T, H), dtype=np.float64) if want_grad else None
+        status = np.empty(T, dtype=np.int32)
+        n_eval = np.empty(T, dtype=np.int32)
+
+        b = L.GpsatBatch()
+        b.T, b.D, b.dtype = T, D, L.F32
+        b.kernel = L.KERNEL_IDS[kernel] if isinstance(kernel, str) else int(kernel)
+        b.memory = L.MEM_DEVICE if device_mode else L.MEM_HOST
+        b.optimiser = L.OPT_IDS[optimiser] if not isinstance(optimiser, int) else optimiser
+        b.max_iter, b.max_ls = int(max_iter), int(max_ls)
+        b.ftol, b.gtol, b.adam_lr = float(ftol), float(gtol), float(adam_lr)
+        b.obs_off, b.pred_off = _ptr(obs_off), _ptr(pred_off)
+        b.theta0, b.lo, b.hi, b.trainable = _ptr(theta0), _ptr(lo), _ptr(hi), _ptr(trainable)
+        b.X, b.y, b.Xs = pX, py, pXs
+        b.theta, b.nll, b.grad = _ptr(theta), _ptr(nll), _ptr(grad)
+        b.status, b.n_eval = _ptr(status), _ptr(n_eval)
+        b.f_mean, b.f_var, b.y_var = pfm, pfv, pyv
+        rc = self._lib.gpsat_fit_predict_batch(self._h, C.byref(b))
+        if rc != 0:
+            raise GpsatError(f"gpsat_fit_predict_batch failed ({rc}): {self._lib.gpsat_last_error().decode()}")
+        km, tm = C.c_double(), C.c_double()
+        self._lib.gpsat_last_timing(self._h, C.byref(km), C.byref(tm))
+        if device_mode:
+            fm, fv, yv = fm[:sumP], fv[:sumP], yv[:sumP]
+        return BatchResult(theta=theta, nll=nll, status=status, n_eval=n_eval, f_mean=fm, f_var=fv, y_var=yv,
+                           grad=grad, kernel_ms=km.value, total_ms=tm.value)
+
+
+_default_engine = None
+
+
+def default_engine() -> Engine:
+    """Process-wide engine on LOCAL_RANK's GPU (one process per GPU)."""
+    global _default_engine
+    if _default_engine is None:
+        import os
+        _default_engine = Engine(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_engine
