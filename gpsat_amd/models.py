@@ -1,0 +1,347 @@
+"""HipGPRModel -- per-tile model class with the reference's BaseGPRModel / GPflowGPRModel interface.
+
+Drop-in hook: the reference selects its backend with ``model_config["oi_model"]``, either a
+registry name or ``{"path_to_model": "gpsat_amd.models", "model_name": "HipGPRModel"}``
+(GPSat/local_experts.py:319-325).  Every method the orchestrator calls on a model
+(GPSat/local_experts.py:1043-1180) exists here with the same name, argument meaning and error
+behaviour as GPSat/models/gpflow_models.py:26-663, but the arithmetic runs in the gfx950 HIP
+kernels through the C ABI (include/gpsat_hip.h).  There is no CPU fallback.
+
+Differences that are deliberate and documented in DESIGN.md:
+  * compute dtype is fp32 on the GPU (host-side scaling / constraints are fp64 like the reference);
+  * ``mean_function`` and ``full_cov=True`` are not built (NotImplementedError);
+  * no TensorFlow import, no per-construction device probe (the engine knows its device).
+"""
+from __future__ import annotations
+
+import platform
+import re
+import warnings
+from typing import Dict, List
+
+import numpy as np
+
+try:  # pandas is optional at import time (arrays may be passed directly)
+    import pandas as pd
+except Exception:  # pragma: no cover
+    pd = None
+
+from . import _lib as L
+
+LIKELIHOOD_VARIANCE_LOWER_BOUND = 1e-6   # GPflow Gaussian likelihood default (gpflow_models.py:404-409)
+
+_cpu_name_cache = None
+
+
+def _processor_name():
+    # base_model.py:302-323 (Linux branch), cached: the reference shells out per construction
+    global _cpu_name_cache
+    if _cpu_name_cache is None:
+        name = platform.processor() or "unknown"
+        try:
+            with open("/proc/cpuinfo") as f:
+                for line in f:
+                    if "model name" in line:
+                        name = re.sub(".*model name.*:", "", line, 1).strip()
+                        break
+        except OSError:
+            pass
+        _cpu_name_cache = name
+    return _cpu_name_cache
+
+
+class HipGPRModel:
+    """Exact GP regression for one expert tile on MI355X (mirror of GPflowGPRModel)."""
+
+    def __init__(self, data=None, coords_col=None, obs_col=None, coords=None, obs=None,
+                 coords_scale=None, obs_scale=None, obs_mean=None, verbose=True, *,
+                 kernel="Matern32", kernel_kwargs=None, mean_function=None, mean_func_kwargs=None,
+                 noise_variance=None, likelihood=None, engine=None, **kwargs):
+        # ---- data intake: GPSat/models/base_model.py:134-189
+        if data is not None:
+            assert coords_col is not None, "data was provided, but coord_col was not"
+            assert obs_col is not None, "data was provided, but obs_col was not"
+            if isinstance(coords_col, str):
+                coords_col = [coords_col]
+            if isinstance(obs_col, str):
+                obs_col = [obs_col]
+            self.obs = np.array(data.loc[:, obs_col].values)
+            self.coords = np.array(data.loc[:, coords_col].values)
+            self.obs_col = obs_col
+            self.coords_col = coords_col
+        else:
+            assert obs is not None, f"data is {data}, and so is obs: {obs}, provide either"
+            assert coords is not None, f"data is {data}, and so is coords: {coords}, provide either"
+            assert isinstance(obs, np.ndarray), "if obs is provided directly it must be an np.array"
+            assert isinstance(coords, np.ndarray), "if obs is provided directly it must be an np.array"
+            obs = np.array(obs)
+            coords = np.array(coords)
+            if len(obs.shape) == 1:
+                obs = obs[:, None]
+            if len(coords.shape) == 1:
+                coords = coords[:, None]
+            assert len(obs) == len(coords), "obs and coords lengths don't match "
+            self.obs = obs
+            self.coords = coords
+            if coords_col is None:
+                coords_col = [_ for _ in range(self.coords.shape[1])]
+            if obs_col is None:
+                obs_col = [0]
+            self.coords_col = coords_col
+            self.obs_col = obs_col
+        assert not np.isnan(self.coords).any(), "nans found in coords"
+        assert not np.isnan(self.obs).any(), "nans found in obs"
+        assert self.obs.shape[1] == 1, "HipGPRModel handles a single observation column"
+
+        # ---- de-mean / scale: base_model.py:195-245 ("local" -> column mean, anything else -> 0)
+        if isinstance(obs_mean, str) and obs_mean == "local":
+            obs_mean = np.mean(self.obs, axis=0)[None, :]
+        else:
+            obs_mean = np.array([0])[None, :]
+        self.obs_mean = np.asarray(obs_mean, dtype=np.float64)
+        if obs_scale is None:
+            obs_scale = np.atleast_2d(1)
+        elif isinstance(obs_scale, list):
+            obs_scale = np.array(obs_scale)[None, :]
+        elif isinstance(obs_scale, (int, float)):
+            obs_scale = np.array([obs_scale])[None, :]
+        self.obs_scale = np.asarray(obs_scale, dtype=np.float64)
+        if coords_scale is None:
+            coords_scale = np.atleast_2d(1)
+        elif isinstance(coords_scale, list):
+            coords_scale = np.array(coords_scale)[None, :]
+        elif isinstance(coords_scale, (int, float)):
+            coords_scale = np.array([coords_scale])[None, :]
+        self.coords_scale = np.asarray(coords_scale, dtype=np.float64)
+        self.coords = self.coords.astype(np.float64) / self.coords_scale
+        self.obs = (self.obs.astype(np.float64) - self.obs_mean) / self.obs_scale
+
+        # ---- kernel / defaults: gpflow_models.py:113-157
+        assert kernel is not None, "kernel was not provided"
+        if not isinstance(kernel, str) or kernel not in L.KERNEL_IDS:
+            raise NotImplementedError(f"kernel {kernel!r}: this backend builds {sorted(L.KERNEL_IDS)}")
+        if mean_function is not None or likelihood is not None:
+            raise NotImplementedError("mean_function / custom likelihood are not built in the HIP backend")
+        self.kernel = kernel
+        D = self.coords.shape[1]
+        if D > 3:
+            raise NotImplementedError("HIP backend is built for 1..3 input dimensions")
+        self.D = D
+        kk = dict(kernel_kwargs or {})
+        ls = np.broadcast_to(np.asarray(kk.get("lengthscales", np.ones(D)), dtype=np.float64), (D,)).copy()
+        self._theta = np.concatenate([ls, [float(kk.get("variance", 1.0))],
+                                      [1.0 if noise_variance is None else float(noise_variance)]])
+        self._lo = np.full(D + 2, np.nan)
+        self._hi = np.full(D + 2, np.nan)
+        self._trainable = np.ones(D + 2, dtype=bool)
+
+        # ---- device info: base_model.py:259 (attributes the orchestrator reads at local_experts.py:1180)
+        from .engine import default_engine
+        self._engine = engine if engine is not None else default_engine()
+        self.gpu_name = self._engine.device_name
+        self.cpu_name = _processor_name()
+        self.n_eval = 0
+        self.status = None
+
+        # base_model.py:270-277
+        for pn in self.param_names:
+            assert not bool(re.search(" ", pn)), f"param_name: '{pn}' has a space (' ') in it, which is prohibited"
+            getattr(self, f"set_{pn}")
+            getattr(self, f"get_{pn}")
+
+    # ------------------------------------------------------------------ interface
+    @property
+    def param_names(self) -> List[str]:
+        return ["lengthscales", "kernel_variance", "likelihood_variance"]
+
+    def get_parameters(self, *args, return_dict=True):
+        # base_model.py:370-403
+        if len(args) == 0:
+            args = self.param_names
+        for a in args:
+            assert a in self.param_names, f"cannot get parameters for: {a}, it's not in param_names: {self.param_names}"
+        if return_dict:
+            return {a: getattr(self, f"get_{a}")() for a in args}
+        return [getattr(self, f"get_{a}")() for a in args]
+
+    def set_parameters(self, **kwargs):
+        # base_model.py:405-422
+        for k, v in kwargs.items():
+            assert k in self.param_names, f"cannot get parameters for: {k}, it's not in param_names: {self.param_names}"
+            getattr(self, f"set_{k}")(v)
+
+    def set_parameter_constraints(self, constraints_dict, **kwargs):
+        # base_model.py:424-439
+        for k, v in constraints_dict.items():
+            assert k in self.param_names, f"cannot get parameters for: {k}, it's not in param_names: {self.param_names}"
+            getattr(self, f"set_{k}_constraints")(**v, **kwargs)
+
+    # -- getters / setters: gpflow_models.py:339-411
+    def get_lengthscales(self) -> np.ndarray:
+        return self._theta[:self.D].copy()
+
+    def get_kernel_variance(self) -> float:
+        return float(self._theta[self.D])
+
+    def get_likelihood_variance(self) -> float:
+        return float(self._theta[self.D + 1])
+
+    def set_lengthscales(self, lengthscales):
+        v = np.asarray(lengthscales, dtype=np.float64).reshape(-1)
+        assert len(v) in (1, self.D), f"lengthscales must have length 1 or {self.D}"
+        self._theta[:self.D] = v
+
+    def set_kernel_variance(self, kernel_variance):
+        if isinstance(kernel_variance, np.ndarray):
+            assert (len(kernel_variance) == 1) & (len(kernel_variance.shape) == 1), \
+                f"set_kernel_variance expected to receive float, or np.array with len(1), shape:(1,), got" \
+                f"len: {len(kernel_variance)}, shape: {kernel_variance.shape}"
+            kernel_variance = kernel_variance[0]
+        self._theta[self.D] = float(kernel_variance)
+
+    def set_likelihood_variance(self, likelihood_variance):
+        if isinstance(likelihood_variance, np.ndarray):
+            assert (len(likelihood_variance) == 1) & (len(likelihood_variance.shape) == 1), \
+                f"set_likelihood_variance expected to receive float, or np.array with len(1), shape:(1,), got" \
+                f"len: {len(likelihood_variance)}, shape: {likelihood_variance.shape}"
+            likelihood_variance = likelihood_variance[0]
+        unconstrained = not np.isfinite(self._lo[self.D + 1])
+        if unconstrained and likelihood_variance < LIKELIHOOD_VARIANCE_LOWER_BOUND:
+            warnings.warn("\n***\ntrying to set likelihood_variance to value less than "
+                          "model.likelihood.variance_lower_bound\nwill set to variance_lower_bound\n***\n")
+            likelihood_variance = LIKELIHOOD_VARIANCE_LOWER_BOUND
+        self._theta[self.D + 1] = float(likelihood_variance)
+
+    # -- constraints: gpflow_models.py:416-590
+    def _slice(self, name):
+        D = self.D
+        return {"lengthscales": slice(0, D), "kernel_variance": slice(D, D + 1),
+                "likelihood_variance": slice(D + 1, D + 2)}[name]
+
+    def _set_param_constraints(self, name, low, high, move_within_tol=True, tol=1e-8, scale=False,
+                               scale_magnitude=None):
+        if isinstance(low, (list, tuple)):
+            low = np.array(low, dtype=np.float64)
+        elif isinstance(low, (int, np.integer, float)):
+            low = np.array([low], dtype=np.float64)
+        if isinstance(high, (list, tuple)):
+            high = np.array(high, dtype=np.float64)
+        elif isinstance(high, (int, np.integer, float)):
+            high = np.array([high], dtype=np.float64)
+        low = np.asarray(low, dtype=np.float64)
+        high = np.asarray(high, dtype=np.float64)
+        assert len(low.shape) == 1
+        assert len(high.shape) == 1
+        sl = self._slice(name)
+        param_vals = np.atleast_1d(self._theta[sl].copy())
+        assert len(param_vals) == len(low), "len of low constraint does not match param length"
+        assert len(param_vals) == len(high), "len of high constraint does not match param length"
+        assert np.all(low <= high), "all values in high constraint must be greater than low"
+        if scale:
+            if scale_magnitude is None:
+                low = low / self.coords_scale[0, :]
+                high = high / self.coords_scale[0, :]
+            else:
+                low = low / scale_magnitude
+                high = high / scale_magnitude
+        if move_within_tol:
+            half_min_width = np.min((high - low)) / 2
+            if tol > half_min_width:
+                tol = half_min_width
+            param_vals[param_vals > (high - tol)] = high[param_vals > (high - tol)] - tol
+            param_vals[param_vals < (low + tol)] = low[param_vals < (low + tol)] + tol
+        self._theta[sl] = param_vals
+        self._lo[sl] = low
+        self._hi[sl] = high
+
+    def set_lengthscales_constraints(self, low, high, move_within_tol=True, tol=1e-8, scale=False, scale_magnitude=None):
+        self._set_param_constraints("lengthscales", low, high, move_within_tol, tol, scale, scale_magnitude)
+
+    def set_kernel_variance_constraints(self, low, high, move_within_tol=True, tol=1e-8, scale=False, scale_magnitude=None):
+        self._set_param_constraints("kernel_variance", low, high, move_within_tol, tol, scale, scale_magnitude)
+
+    def set_likelihood_variance_constraints(self, low, high, move_within_tol=True, tol=1e-8, scale=False, scale_magnitude=None):
+        self._set_param_constraints("likelihood_variance", low, high, move_within_tol, tol, scale, scale_magnitude)
+
+    # -- the three device calls
+    def _run(self, *, optimiser, max_iter=0, pred_coords=None, **opt_kwargs):
+        N, D = self.coords.shape
+        P = 0 if pred_coords is None else len(pred_coords)
+        Xs = np.zeros((0, D), dtype=np.float32) if pred_coords is None else pred_coords.astype(np.float32)
+        return self._engine.fit_predict_batch(
+            D=D, obs_off=np.array([0, N]), X=self.coords.astype(np.float32), y=self.obs[:, 0].astype(np.float32),
+            pred_off=np.array([0, P]), Xs=Xs, theta0=self._theta[None, :], lo=self._lo[None, :],
+            hi=self._hi[None, :], trainable=self._trainable, kernel=self.kernel, optimiser=optimiser,
+            max_iter=max_iter, **opt_kwargs)
+
+    def _fix_hyperparameters(self, params_list):
+        # gpflow_models.py:275-288
+        for param in params_list:
+            if param in self.param_names:
+                self._trainable[self._slice(param)] = False
+            else:
+                print(f"{param} is not detected as a hyperparameter. Skipping...")
+
+    def optimise_parameters(self, max_iter=10_000, fixed_params=None, **opt_kwargs):
+        """L-BFGS on the unconstrained parameters, entirely on the GPU
+        (replaces gpflow.optimizers.Scipy().minimize, gpflow_models.py:291-329).
+        Returns True when the optimiser converged within ``max_iter`` (scipy ``success``)."""
+        if fixed_params is None:
+            fixed_params = []
+        self._fix_hyperparameters(fixed_params)
+        optimiser = opt_kwargs.pop("optimiser", "lbfgs")
+        # engine tolerances may be passed through; SciPy-specific keys of the reference are ignored
+        known = {k: opt_kwargs[k] for k in ("max_ls", "ftol", "gtol", "adam_lr") if k in opt_kwargs}
+        r = self._run(optimiser=optimiser, max_iter=max_iter, **known)
+        self.status = int(r.status[0])
+        self.n_eval = int(r.n_eval[0])
+        if self.status in (0, 1):
+            self._theta = r.theta[0].copy()
+        success = self.status == 0
+        if not success:
+            print("*" * 10)
+            print("optimization failed!")
+        return success
+
+    def get_objective_function_value(self):
+        """Negative log marginal likelihood at the current parameters (gpflow_models.py:334-337)."""
+        r = self._run(optimiser="none")
+        return float(r.nll[0])
+
+    def predict(self, coords, full_cov=False, apply_scale=True) -> Dict[str, np.ndarray]:
+        # gpflow_models.py:187-273
+        if pd is not None and isinstance(coords, (pd.Series, pd.DataFrame)):
+            if self.coords_col is not None:
+                coords = coords[self.coords_col].values
+            else:
+                coords = coords.values
+        if isinstance(coords, list):
+            coords = np.array(coords)
+        if len(coords.shape) == 1:
+            coords = coords[None, :]
+        assert isinstance(coords, np.ndarray), "coords should be an ndarray (one can be converted from)"
+        coords = coords.astype(self.coords.dtype)
+        if full_cov:
+            raise NotImplementedError("full_cov=True is not built in the HIP backend")
+        if apply_scale:
+            coords = coords / self.coords_scale
+        r = self._run(optimiser="none", pred_coords=coords)
+        if r.status[0] in (2, 3):
+            raise FloatingPointError("covariance matrix is not positive definite at the current parameters")
+        out = {"f*": r.f_mean.astype(np.float64), "f*_var": r.f_var.astype(np.float64),
+               "y_var": r.y_var.astype(np.float64)}
+        f_bar = self.obs_mean[:, 0]
+        if len(f_bar) != len(out["f*"]):
+            assert len(f_bar) == 1, f"'f_bar' did not match the length of 'f*' and f_bar len is not, got: {len(f_bar)}"
+            out["f_bar"] = np.repeat(f_bar, len(out["f*"]))
+        else:
+            out["f_bar"] = f_bar
+        return out
+
+
+def get_model(name):
+    """Registry hook with the reference's semantics (GPSat/models/__init__.py:3-28): the exact-GP
+    names resolve to the HIP backend; anything else is NotImplementedError."""
+    if name in ("HipGPRModel", "GPflowGPRModel"):
+        return HipGPRModel
+    raise NotImplementedError(f"model with name: '{name}' is not implemented")
