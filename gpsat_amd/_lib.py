@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgpsat_hip.so")
+# GPSAT_LIB: developer override to load the diagnostic build (scripts/phase_profile.py); never a fallback
+LIB_PATH = os.environ.get("GPSAT_LIB") or os.path.join(_HERE, "csrc", "libgpsat_hip.so")
 
 # constants mirrored from include/gpsat_hip.h
 ABI_VERSION = 1

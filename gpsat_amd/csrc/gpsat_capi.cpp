@@ -59,7 +59,8 @@ struct gpsat_handle {
     char name[256] = {0};
     double last_kernel_ms = 0.0, last_total_ms = 0.0;
     // device buffers (grown lazily, owned by the handle)
-    DevBuf meta_i64, meta_f64, meta_misc, out_f64, out_i32, bulk_in, bulk_out, ws;
+    DevBuf meta_i64, meta_f64, meta_misc, out_f64, out_i32, bulk_in, bulk_out, ws, prof;
+    unsigned long long prof_host[64] = {0};
 };
 
 extern "C" {
@@ -110,7 +111,7 @@ int gpsat_destroy(gpsat_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->meta_i64.release(); h->meta_f64.release(); h->meta_misc.release(); h->out_f64.release();
-    h->out_i32.release(); h->bulk_in.release(); h->bulk_out.release(); h->ws.release();
+    h->out_i32.release(); h->bulk_in.release(); h->bulk_out.release(); h->ws.release(); h->prof.release();
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -234,6 +235,12 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     a.f_mean = dfm; a.f_var = dfv; a.y_var = dyv;
     a.order = d_order; a.queue = d_queue;
     a.ws = static_cast<float*>(h->ws.p); a.ws_stride = wsf;
+    a.prof = nullptr;
+#ifdef GPSAT_PROFILE
+    if ((rc = h->prof.reserve(64 * sizeof(unsigned long long)))) return rc;
+    HIP_TRY(hipMemsetAsync(h->prof.p, 0, 64 * sizeof(unsigned long long), h->stream));
+    a.prof = static_cast<unsigned long long*>(h->prof.p);
+#endif
 
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     HIP_TRY(gpsat::launch_tiles(D, a, grid, smem, h->stream));
@@ -249,6 +256,9 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
         HIP_TRY(hipMemcpyAsync(b->f_var, dfv, (size_t)sumP * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipMemcpyAsync(b->y_var, dyv, (size_t)sumP * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     }
+#ifdef GPSAT_PROFILE
+    HIP_TRY(hipMemcpyAsync(h->prof_host, h->prof.p, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+#endif
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     float km = 0.f, tm = 0.f;
@@ -258,5 +268,14 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     h->last_total_ms = tm;
     return GPSAT_OK;
 }
+
+#ifdef GPSAT_PROFILE
+// diagnostic build only: per-wave, per-segment cycle counters of the last call ([4 waves][16 slots])
+int gpsat_debug_profile(gpsat_handle* h, unsigned long long* out64) {
+    if (!h || !out64) return GPSAT_EINVAL;
+    std::memcpy(out64, h->prof_host, sizeof(h->prof_host));
+    return GPSAT_OK;
+}
+#endif
 
 }  // extern "C"

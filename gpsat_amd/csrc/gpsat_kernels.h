@@ -31,6 +31,7 @@ struct KernelArgs {
     int* queue;                   // work-queue head (zeroed before launch)
     float* ws;                    // per-workgroup workspace
     size_t ws_stride;             // floats per workgroup
+    unsigned long long* prof;     // [NW*16] cycle counters (diagnostic build only, else nullptr)
 };
 
 size_t shared_bytes(int D, int NBmax);

@@ -29,19 +29,42 @@
 #include <stdint.h>
 #include "gpsat_kernels.h"
 
+// Diagnostic build only (-DGPSAT_PROFILE, scripts/phase_profile.py): per-wave cycle counters per code
+// segment, accumulated in LDS and flushed to KernelArgs::prof.  No stamp executes in the product build.
+#ifdef GPSAT_PROFILE
+#define PROF_BEGIN() unsigned long long prof_t_ = __builtin_amdgcn_s_memtime()
+#define PROF_END(c_, slot_)                                                                  \
+    do {                                                                                     \
+        unsigned long long t1_ = __builtin_amdgcn_s_memtime();                               \
+        if ((c_).lane == 0) (c_).prof[(c_).w * 16 + (slot_)] += t1_ - prof_t_;               \
+        prof_t_ = t1_;                                                                       \
+    } while (0)
+#else
+#define PROF_BEGIN() do {} while (0)
+#define PROF_END(c_, slot_) do {} while (0)
+#endif
+
 namespace gpsat {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// The whole LDS of a workgroup.  Everything in LDS is addressed as lds_f[offset] so that the compiler
+// always knows the address space (ds_* instructions, never flat_*).
+extern __shared__ __attribute__((aligned(16))) float lds_f[];
+
 __device__ __forceinline__ int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+constexpr int NW = 4;          // waves per workgroup
+constexpr int NT = 256;        // threads per workgroup
+constexpr int BLK = 1024;      // floats per block
+constexpr int HMAX = 6;        // max D + 2 (D <= 4)
+constexpr int MH = 8;          // L-BFGS history
 
 // ---------------------------------------------------------------------------------------------
 // block movement (acc layout) and the MFMA chain
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ f32x16 load_blk(const float* __restrict__ p, int lane) {
-    const f32x4* q = reinterpret_cast<const f32x4*>(p) + lane;
-    f32x4 a = q[0], b = q[64], c = q[128], d = q[192];
+__device__ __forceinline__ f32x16 pack16(const f32x4& a, const f32x4& b, const f32x4& c, const f32x4& d) {
     f32x16 r;
     r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
     r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
@@ -50,8 +73,27 @@ __device__ __forceinline__ f32x16 load_blk(const float* __restrict__ p, int lane
     return r;
 }
 
-__device__ __forceinline__ void store_blk(float* __restrict__ p, int lane, const f32x16& v) {
-    f32x4* q = reinterpret_cast<f32x4*>(p) + lane;
+// global block `blk` of the workgroup's workspace
+__device__ __forceinline__ f32x16 ldg(const float* __restrict__ ws, int blk, int lane) {
+    const f32x4* q = reinterpret_cast<const f32x4*>(ws + (size_t)blk * BLK) + lane;
+    return pack16(q[0], q[64], q[128], q[192]);
+}
+
+__device__ __forceinline__ void stg(float* __restrict__ ws, int blk, int lane, const f32x16& v) {
+    f32x4* q = reinterpret_cast<f32x4*>(ws + (size_t)blk * BLK) + lane;
+    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    f32x4 c = {v[8], v[9], v[10], v[11]}, d = {v[12], v[13], v[14], v[15]};
+    q[0] = a; q[64] = b; q[128] = c; q[192] = d;
+}
+
+// LDS block at float offset `off` (16-byte aligned)
+__device__ __forceinline__ f32x16 ldl(int off, int lane) {
+    const f32x4* q = reinterpret_cast<const f32x4*>(lds_f + off) + lane;
+    return pack16(q[0], q[64], q[128], q[192]);
+}
+
+__device__ __forceinline__ void stl(int off, int lane, const f32x16& v) {
+    f32x4* q = reinterpret_cast<f32x4*>(lds_f + off) + lane;
     f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
     f32x4 c = {v[8], v[9], v[10], v[11]}, d = {v[12], v[13], v[14], v[15]};
     q[0] = a; q[64] = b; q[128] = c; q[192] = d;
@@ -78,9 +120,22 @@ __device__ __forceinline__ float xhalf_sum(float v) {   // v(lane) + v(lane ^ 32
     return v + __shfl_xor(v, 32);
 }
 
+__device__ __forceinline__ void wave_lds_sync() {       // LDS is in-order per wave: only the compiler must not reorder
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// one wave pulls the next work index from an LDS counter (wave-uniform result)
+__device__ __forceinline__ int wave_pull(int* counter, int lane) {
+    int v = 0;
+    if (lane == 0) v = atomicAdd(counter, 1);
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
 // ---------------------------------------------------------------------------------------------
 // covariance functions.  r2 is the squared scaled distance.
-//   kf = k(r) / 1 , gg = g(r) with dk/dl_d = g(r) (x_d-x'_d)^2 / l_d^3   (both without sigma_f^2)
+//   kf = k(r), gg = g(r) with dk/dl_d = g(r) (x_d-x'_d)^2 / l_d^3   (both without sigma_f^2)
 // ---------------------------------------------------------------------------------------------
 template <int KERN>
 __device__ __forceinline__ void kfun(float r2, float& kf, float& gg) {
@@ -107,14 +162,8 @@ __device__ __forceinline__ void kfun(float r2, float& kf, float& gg) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-workgroup context
+// per-workgroup state
 // ---------------------------------------------------------------------------------------------
-constexpr int NW = 4;          // waves per workgroup
-constexpr int NT = 256;        // threads per workgroup
-constexpr int BLK = 1024;      // floats per block
-constexpr int HMAX = 6;        // max D + 2 (D <= 4)
-constexpr int MH = 8;          // L-BFGS history
-
 struct Shared {
     // evaluation interface
     double theta[HMAX];
@@ -137,17 +186,29 @@ struct Shared {
     int box[HMAX];
     int fail, done, status, n_eval, n_eval_opt, iter, phase, want_grad;
     int tile;
+    int g0done;                 // slot index up to which group 0 of the previous panel is in memory
+    int gnext[2];               // dynamic group queue heads of the PT slots (alternating) 
+    int gradnext;               // dynamic group queue head of the gradient phase
+    unsigned long long prof[NW * 16];
 };
+
+constexpr int SHARED_FLOATS = (int)((sizeof(Shared) + 15) / 16) * 4;
+
+__device__ __forceinline__ Shared* shared_state() { return reinterpret_cast<Shared*>(lds_f); }
+
+// float offsets into lds_f
+struct Lay { int xs, xsc, y, z, alpha, Ad, LT, U01, tmp, piv; };
 
 template <int D>
 struct Ctx {
-    float *xs, *xsc, *y, *z, *alpha, *Ad, *LinvT, *tmp;
-    Shared* sh;
-    float *U, *Dinv, *DinvT, *Vs;
+    Lay L;
+    float* ws;                   // this workgroup's global workspace
+    int zb, dT0, vs0;            // block indices: zero block, DinvT[0], V scratch
     int N, NB, Npad, P;
     int tid, lane, w, h, g;
     float sf2, sn2;
     int kern;
+    unsigned long long* prof;    // LDS, [NW][16] (diagnostic build)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -160,7 +221,7 @@ __device__ __forceinline__ f32x16 kblock_t(const Ctx<D>& c, int bi, int bj) {
     const int q = 32 * bj + c.g;
     float xq[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) xq[d] = c.xsc[d * c.Npad + q];
+    for (int d = 0; d < D; ++d) xq[d] = lds_f[c.L.xsc + d * c.Npad + q];
     f32x16 out;
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
@@ -168,7 +229,7 @@ __device__ __forceinline__ f32x16 kblock_t(const Ctx<D>& c, int bi, int bj) {
         float r2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            f32x4 xp = *reinterpret_cast<const f32x4*>(c.xsc + d * c.Npad + p0);
+            f32x4 xp = *reinterpret_cast<const f32x4*>(lds_f + c.L.xsc + d * c.Npad + p0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { float df = xp[e] - xq[d]; r2[e] = fmaf(df, df, r2[e]); }
         }
@@ -197,7 +258,7 @@ __device__ __forceinline__ f32x16 kblock(const Ctx<D>& c, int bi, int bj) {
     }
 }
 
-// cross-covariance block: rows = observations 32*bj.., cols = prediction points 32*pc.. (xq scaled)
+// cross-covariance block: rows = observations 32*bj.., cols = prediction points (xq scaled)
 template <int D, int KERN>
 __device__ __forceinline__ f32x16 ksblock_t(const Ctx<D>& c, int bj, const float (&xq)[D], bool qvalid) {
     f32x16 out;
@@ -207,7 +268,7 @@ __device__ __forceinline__ f32x16 ksblock_t(const Ctx<D>& c, int bj, const float
         float r2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            f32x4 xp = *reinterpret_cast<const f32x4*>(c.xsc + d * c.Npad + p0);
+            f32x4 xp = *reinterpret_cast<const f32x4*>(lds_f + c.L.xsc + d * c.Npad + p0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { float df = xp[e] - xq[d]; r2[e] = fmaf(df, df, r2[e]); }
         }
@@ -241,37 +302,41 @@ __device__ __forceinline__ void contract_t(const Ctx<D>& c, const f32x16& kinv, 
     const int q = 32 * bb + c.g;
     float xq[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) xq[d] = c.xsc[d * c.Npad + q];
-    const float aq = c.alpha[q];
+    for (int d = 0; d < D; ++d) xq[d] = lds_f[c.L.xsc + d * c.Npad + q];
+    const float aq = lds_f[c.L.alpha + q];
     const bool qv = q < c.N;
+    // all LDS operands of the block first (independent reads in flight together), then the arithmetic
+    f32x4 xp[4][D], ap[4];
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
         const int p0 = 32 * ba + 8 * qq + 4 * c.h;
-        float r2[4] = {0.f, 0.f, 0.f, 0.f};
-        float d2[D][4];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            f32x4 xp = *reinterpret_cast<const f32x4*>(c.xsc + d * c.Npad + p0);
+        for (int d = 0; d < D; ++d) xp[qq][d] = *reinterpret_cast<const f32x4*>(lds_f + c.L.xsc + d * c.Npad + p0);
+        ap[qq] = *reinterpret_cast<const f32x4*>(lds_f + c.L.alpha + p0);
+    }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float df = xp[e] - xq[d];
-                d2[d][e] = df * df;
-                r2[e] += d2[d][e];
-            }
-        }
-        f32x4 ap = *reinterpret_cast<const f32x4*>(c.alpha + p0);
+    for (int qq = 0; qq < 4; ++qq) {
+        const int p0 = 32 * ba + 8 * qq + 4 * c.h;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int p = p0 + e;
+            float d2[D];
+            float r2 = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float df = xp[qq][d][e] - xq[d];
+                d2[d] = df * df;
+                r2 += d2[d];
+            }
             float kf, gg;
-            kfun<KERN>(r2[e], kf, gg);
-            float Q = kinv[4 * qq + e] - ap[e] * aq;
+            kfun<KERN>(r2, kf, gg);
+            float Q = kinv[4 * qq + e] - ap[qq][e] * aq;
             Q = (qv && p < c.N) ? Q : 0.f;
             const float wq = wgt * Q;
             accsf = fmaf(wq, kf, accsf);
             const float wg = wq * gg;
 #pragma unroll
-            for (int d = 0; d < D; ++d) accl[d] = fmaf(wg, d2[d][e], accl[d]);
+            for (int d = 0; d < D; ++d) accl[d] = fmaf(wg, d2[d], accl[d]);
             if (p == q) accsn += Q;
         }
     }
@@ -289,64 +354,98 @@ __device__ __forceinline__ void contract(const Ctx<D>& c, const f32x16& kinv, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// 32x32 diagonal block: Cholesky W = L L^T and X = L^-1, one wave, registers + cross-lane reads.
-// In : W (acc layout).  Out: S1 = X in acc layout, S2 = X^T in acc layout, Ad = X row-major [32][33]
-//      logsum = sum log L_kk, bad = 1 when a pivot is not positive (or NaN).
+// 32x32 diagonal block: X with X W X^T = I ("L^-1"; only X and X^T are ever used, X need not be
+// triangular), one wave, all 64 lanes.
+// Block Gaussian elimination with 2x2 pivots (W is SPD, no pivoting) of the augmented [W | I]:
+// W = Lb Db Lb^T, [W | I] -> [.. | Lb^-1], then X = Cb^-1 Lb^-1 with Db = Cb Cb^T (2x2 Cholesky per
+// pivot block).  Lane (i, h) owns row i and the augmented columns of parity h (32 registers).  At step
+// s the two pivot columns 2s, 2s+1 sit in register s of the two halves, the live window is registers
+// s+1..s+16 of every lane, and the two pivot rows are broadcast through a 64-float LDS buffer:
+// 16 dependent steps instead of 32 pivots + 32 triangular-inverse columns.
+// In : W (acc layout).  Out: S1 = X (acc layout), S2 = X^T (acc layout), logsum = -log|det X| (fp64),
+//      bad = 1 when a pivot block is not positive definite (or NaN).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void diag_factor(const f32x16& W, float* __restrict__ Ad, int lane, f32x16& S1, f32x16& S2,
-                                         double& logsum, int& bad) {
-    const int h = lane >> 5, g = lane & 31;
+__device__ __forceinline__ float lane_xor32(float x, int h) {
+    // value of lane ^ 32 (v_permlane32_swap: VALU, no LDS round trip)
+    const unsigned u = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(h ? r[0] : r[1]);
+}
+
+__device__ __forceinline__ void diag_factor(const f32x16& W, int Ad, int piv, int lane, f32x16& S1, f32x16& S2,
+                                            double& logsum, int& bad) {
+    const int h = lane >> 5, i = lane & 31;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Ad[rho(r, h) * 33 + g] = W[r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int r = 0; r < 16; ++r) lds_f[Ad + rho(r, h) * 33 + i] = W[r];
+    wave_lds_sync();
     float a[32];
 #pragma unroll
-    for (int cc = 0; cc < 32; ++cc) a[cc] = Ad[g * 33 + cc];   // lane g (and its mirror g+32) holds row g
+    for (int q = 0; q < 16; ++q) a[q] = lds_f[Ad + i * 33 + 2 * q + h];        // W[i][2q+h]
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a[16 + q] = (2 * q + h == i) ? 1.f : 0.f;      // I[i][2q+h]
     int isbad = 0;
-    float mydiag = 1.f;
+    float mp00 = 1.f, mp10 = 0.f, mp11 = 1.f;        // this lane's pivot block (rows i & ~1, i | 1)
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        float dk = readlane_f(a[k], k);
-        if (!(dk > 0.f)) { isbad = 1; dk = 1.f; }
-        const float sd = sqrtf(dk);
-        const float iv = 1.0f / sd;
-        mydiag = (g == k) ? sd : mydiag;
-        a[k] *= iv;                                  // column k of L (rows >= k)
+    for (int s = 0; s < 16; ++s) {
+        const int k0 = 2 * s, k1 = k0 + 1;
+        // 2x2 pivot block: columns k0 (half 0) and k1 (half 1) live in register s
+        float p00 = readlane_f(a[s], k0);
+        float p10 = readlane_f(a[s], k1);
+        float p11 = readlane_f(a[s], k1 + 32);
+        float det = p00 * p11 - p10 * p10;
+        if (!(p00 > 0.f) || !(det > 0.f)) { isbad = 1; p00 = 1.f; p10 = 0.f; p11 = 1.f; det = 1.f; }
+        float rd = __builtin_amdgcn_rcpf(det);
+        rd = rd * (2.f - det * rd);
+        rd = rd * (2.f - det * rd);
+        const bool mine = (i >> 1) == s;
+        mp00 = mine ? p00 : mp00;
+        mp10 = mine ? p10 : mp10;
+        mp11 = mine ? p11 : mp11;
+        // this row's entries in the two pivot columns, then [m0 m1] = [w0 w1] P^-1
+        const float other = lane_xor32(a[s], h);
+        const float w0 = h ? other : a[s];
+        const float w1 = h ? a[s] : other;
+        float m0 = (w0 * p11 - w1 * p10) * rd;
+        float m1 = (w1 * p00 - w0 * p10) * rd;
+        const bool below = i > k1;
+        m0 = below ? m0 : 0.f;
+        m1 = below ? m1 : 0.f;
+        // pivot rows (live registers s+1 .. s+16 of lanes k0, k1 in both halves) -> LDS -> everybody
+        if (mine) {
 #pragma unroll
-        for (int cc = k + 1; cc < 32; ++cc) {
-            const float lck = readlane_f(a[k], cc);  // L[cc][k]
-            a[cc] = fmaf(-a[k], lck, a[cc]);
+            for (int t = 0; t < 16; ++t) lds_f[piv + 32 * h + 16 * (i & 1) + t] = a[s + 1 + t];
         }
-    }
-    // X = L^-1, lane g computes column g of X
-    float x[32];
+        wave_lds_sync();
+        float r0[16], r1[16];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        float s = (g == i) ? 1.f : 0.f;
+        for (int t = 0; t < 16; ++t) { r0[t] = lds_f[piv + 32 * h + t]; r1[t] = lds_f[piv + 32 * h + 16 + t]; }
 #pragma unroll
-        for (int cc = 0; cc < i; ++cc) s = fmaf(-readlane_f(a[cc], i), x[cc], s);   // L[i][cc]
-        x[i] = s / readlane_f(a[i], i);
+        for (int t = 0; t < 16; ++t) a[s + 1 + t] = fmaf(-m1, r1[t], fmaf(-m0, r0[t], a[s + 1 + t]));
+        wave_lds_sync();
     }
-    // S1[r] on lane (h,g) = X[rho(r,h)][g]
+    // 2x2 Cholesky of this lane's pivot block: C = [[c00,0],[c10,c11]], C^-1 = [[1/c00,0],[-c10/(c00 c11),1/c11]]
+    const float c00 = sqrtf(mp00);
+    const float c10 = mp10 / c00;
+    const float c11 = sqrtf(mp11 - c10 * c10);
+    const float i00 = 1.0f / c00, i11 = 1.0f / c11;
+    const float i10 = -c10 * i00 * i11;
+    // X row i: even row  -> i00 * E[i];  odd row -> i10 * E[i-1] + i11 * E[i]   (E = Lb^-1, lane i-1 via DPP row_shr:1)
+    const bool odd = (i & 1) != 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const float e = a[16 + q];
+        const float up = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(e), 0x111, 0xf, 0xf, true));
+        const float x = odd ? fmaf(i10, up, i11 * e) : i00 * e;
+        lds_f[Ad + i * 33 + 2 * q + h] = x;
+    }
+    wave_lds_sync();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int r0 = (r & 3) + 8 * (r >> 2);
-        S1[r] = h ? x[r0 + 4] : x[r0];
+        S1[r] = lds_f[Ad + rho(r, h) * 33 + i];     // X[rho][g]
+        S2[r] = lds_f[Ad + i * 33 + rho(r, h)];     // X^T in acc layout
     }
-    __builtin_amdgcn_wave_barrier();
-    if (h == 0) {
-#pragma unroll
-        for (int i = 0; i < 32; ++i) Ad[i * 33 + g] = x[i];          // row-major X
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int r = 0; r < 16; ++r) S2[r] = Ad[g * 33 + rho(r, h)];      // X^T in acc layout
-    // sum log L_kk in fp64: lane k (< 32) owns pivot k
-    double lg = (h == 0) ? log((double)mydiag) : 0.0;
+    // -log|det X| = sum log(c00 c11) over pivot blocks, fp64; even lanes of half 0 own one block each
+    double lg = (h == 0 && !odd) ? log((double)c00 * (double)c11) : 0.0;
 #pragma unroll
     for (int off = 16; off >= 1; off >>= 1) lg += __shfl_xor(lg, off);
     logsum = __shfl(lg, 0);
@@ -354,186 +453,358 @@ __device__ __forceinline__ void diag_factor(const f32x16& W, float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// phase 1: blocked Cholesky (upper, K = U^T U) with fused K build and forward solve z = L^-1 y
+// phase PT: blocked Cholesky K = U^T U (upper) and, in the same sweep, M = L^-1 (lower), processed
+// by 2-row panels (rows j0, j0+1).  A panel's work items are block columns: U-type i > j1 and (when
+// the gradient is wanted) M-type c < j0; a wave processes groups of 2 columns x 2 rows (4
+// accumulators) with register double-buffering: the 4 blocks of step k+1 are in flight while the 64
+// MFMAs of step k issue.  The panel blocks U_k,j0 / U_k,j1 are common to all waves (L1/L2 hits).
+//   U-type column i > j1 : W_r = K_jr,i - sum_{k<j0} U_k,jr^T U_ki
+//   M-type column c < j0 : W_r =        - sum_{k=c}^{j0-1} U_k,jr^T M_kc        (M_cc = L_cc^-1)
+//   row j0 : X_j0 = L_j0j0^-1 W_0 ;  row j1 : X_j1 = L_j1j1^-1 (W_1 - U_j0j1^T X_j0)
+// Wave 0 owns the 2x2 diagonal part (both 32x32 factorisations), the forward solve z = L^-1 y and the
+// block M_j1,j0.  alpha = M^T z is accumulated as the M blocks are produced.
+// Storage: U_ki (k < i) in the upper half of an NB x NB square of blocks, M_ik (i > k) in the lower
+// half, M_kk = L_kk^-1 on the diagonal; (L_kk^-1)^T in a side array (DinvT).
 // ---------------------------------------------------------------------------------------------
 template <int D>
-__device__ __forceinline__ void phase_potrf(Ctx<D>& c) {
-    Shared* sh = c.sh;
-    const int NB = c.NB, lane = c.lane, w = c.w;
-    if (c.tid == 0) { sh->logdet = 0.0; sh->fail = 0; }
-    __syncthreads();
-    for (int j = 0; j < NB; ++j) {
-        const int nOff = NB - 1 - j;             // off-diagonal blocks of row j: i = j+1+idx
-        // ---- step 1: wave 0 -> diagonal block; waves 1..3 -> first pair of off-diagonal blocks
-        f32x16 W0 = zero16(), W1 = zero16();
-        int i0 = -1, i1 = -1;
-        if (w == 0) {
-            float tp = 0.f;
-            for (int k = 0; k < j; ++k) {
-                f32x16 A = load_blk(c.U + (size_t)(k * NB + j) * BLK, lane);
-                mma_blk(W0, A, A);
+struct Panel {
+    int j0, j1, has1, nU, nItems;
+};
+
+template <int D>
+__device__ __forceinline__ int pt_item_col(const Panel<D>& p, int e) { return (e < p.nU) ? (p.j1 + 1 + e) : (e - p.nU); }
+
+// k-loop of the group holding items 2g, 2g+1: on return W[2r+n] is the finished right-hand side of
+// row jr, item n.
+template <int D>
+__device__ __forceinline__ void pt_group_kloop(const Ctx<D>& c, const Panel<D>& p, int g, f32x16 (&W)[4]) {
+    const int NB = c.NB, lane = c.lane, j0 = p.j0;
+    const int e0 = 2 * g, e1 = e0 + 1;
+    const bool v0 = e0 < p.nItems, v1 = e1 < p.nItems;
+    const bool u0 = e0 < p.nU, u1 = e1 < p.nU;
+    const int c0 = v0 ? pt_item_col(p, e0) : 0, c1 = v1 ? pt_item_col(p, e1) : 0;
+    const int ks0 = v0 ? (u0 ? 0 : c0) : j0, ks1 = v1 ? (u1 ? 0 : c1) : j0;
+    const int kmin = min(ks0, ks1);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tp = fmaf(A[r], c.z[32 * k + rho(r, c.h)], tp);
+    for (int n = 0; n < 4; ++n) W[n] = zero16();
+    if (kmin < j0) {
+        f32x16 A0 = ldg(c.ws, kmin * NB + j0, lane);
+        f32x16 A1 = ldg(c.ws, p.has1 ? kmin * NB + p.j1 : c.zb, lane);
+        f32x16 B0 = ldg(c.ws, (kmin >= ks0) ? kmin * NB + c0 : c.zb, lane);
+        f32x16 B1 = ldg(c.ws, (kmin >= ks1) ? kmin * NB + c1 : c.zb, lane);
+        for (int k = kmin; k < j0; ++k) {
+            f32x16 nA0 = A0, nA1 = A1, nB0 = B0, nB1 = B1;
+            if (k + 1 < j0) {
+                const int kn = k + 1;
+                nA0 = ldg(c.ws, kn * NB + j0, lane);
+                nA1 = ldg(c.ws, p.has1 ? kn * NB + p.j1 : c.zb, lane);
+                nB0 = ldg(c.ws, (kn >= ks0) ? kn * NB + c0 : c.zb, lane);
+                nB1 = ldg(c.ws, (kn >= ks1) ? kn * NB + c1 : c.zb, lane);
             }
-            f32x16 Kd = kblock<D>(c, j, j);
-            f32x16 Wd = Kd - W0;
-            f32x16 S1, S2;
-            double ls; int bad;
-            diag_factor(Wd, c.Ad, lane, S1, S2, ls, bad);
-            store_blk(c.Dinv + (size_t)j * BLK, lane, S1);
-            store_blk(c.DinvT + (size_t)j * BLK, lane, S2);
-            store_blk(c.LinvT, lane, S2);
-            // z_j = L_jj^-1 (y_j - t_j)
-            const float t = xhalf_sum(tp);
-            if (c.h == 0) c.tmp[c.g] = c.y[32 * j + c.g] - t;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            float zz = 0.f;
-#pragma unroll
-            for (int cc = 0; cc < 32; ++cc) zz = fmaf(c.Ad[c.g * 33 + cc], c.tmp[cc], zz);
-            if (c.h == 0) c.z[32 * j + c.g] = zz;
-            if (lane == 0) { sh->logdet += ls; if (bad) sh->fail = 1; }
-            W0 = zero16(); W1 = zero16();
-        } else {
-            const int idx0 = 2 * (w - 1), idx1 = idx0 + 1;
-            if (idx0 < nOff) i0 = j + 1 + idx0;
-            if (idx1 < nOff) i1 = j + 1 + idx1;
-            if (i0 >= 0) {
-                for (int k = 0; k < j; ++k) {
-                    f32x16 A = load_blk(c.U + (size_t)(k * NB + j) * BLK, lane);
-                    f32x16 B0 = load_blk(c.U + (size_t)(k * NB + i0) * BLK, lane);
-                    mma_blk(W0, A, B0);
-                    if (i1 >= 0) {
-                        f32x16 B1 = load_blk(c.U + (size_t)(k * NB + i1) * BLK, lane);
-                        mma_blk(W1, A, B1);
-                    }
-                }
-                W0 = kblock<D>(c, j, i0) - W0;
-                if (i1 >= 0) W1 = kblock<D>(c, j, i1) - W1;
-            }
+            mma_blk(W[0], A0, B0);
+            mma_blk(W[1], A0, B1);
+            mma_blk(W[2], A1, B0);
+            mma_blk(W[3], A1, B1);
+            A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
         }
-        __syncthreads();
-        if (sh->fail) break;
-        // ---- step 2: apply L_jj^-1 and store; then the remaining pairs over all 4 waves
-        const f32x16 Lop = load_blk(c.LinvT, lane);
-        if (i0 >= 0) {
-            f32x16 Uo = zero16();
-            mma_blk(Uo, Lop, W0);
-            store_blk(c.U + (size_t)(j * NB + i0) * BLK, lane, Uo);
-            if (i1 >= 0) {
-                f32x16 Uo1 = zero16();
-                mma_blk(Uo1, Lop, W1);
-                store_blk(c.U + (size_t)(j * NB + i1) * BLK, lane, Uo1);
-            }
-        }
-        for (int idx = 2 * (NW - 1) + 2 * w; idx < nOff; idx += 2 * NW) {
-            const int a0 = j + 1 + idx;
-            const int a1 = (idx + 1 < nOff) ? a0 + 1 : -1;
-            f32x16 V0 = zero16(), V1 = zero16();
-            for (int k = 0; k < j; ++k) {
-                f32x16 A = load_blk(c.U + (size_t)(k * NB + j) * BLK, lane);
-                f32x16 B0 = load_blk(c.U + (size_t)(k * NB + a0) * BLK, lane);
-                mma_blk(V0, A, B0);
-                if (a1 >= 0) {
-                    f32x16 B1 = load_blk(c.U + (size_t)(k * NB + a1) * BLK, lane);
-                    mma_blk(V1, A, B1);
-                }
-            }
-            V0 = kblock<D>(c, j, a0) - V0;
-            f32x16 Uo = zero16();
-            mma_blk(Uo, Lop, V0);
-            store_blk(c.U + (size_t)(j * NB + a0) * BLK, lane, Uo);
-            if (a1 >= 0) {
-                V1 = kblock<D>(c, j, a1) - V1;
-                f32x16 Uo1 = zero16();
-                mma_blk(Uo1, Lop, V1);
-                store_blk(c.U + (size_t)(j * NB + a1) * BLK, lane, Uo1);
-            }
-        }
-        __syncthreads();
     }
-    __syncthreads();
+    // U-type: W = K - acc ; M-type: W = -acc
+    if (v0 && u0) {
+        W[0] = kblock<D>(c, j0, c0) - W[0];
+        if (p.has1) W[2] = kblock<D>(c, p.j1, c0) - W[2];
+    } else {
+        W[0] = -W[0];
+        W[2] = -W[2];
+    }
+    if (v1 && u1) {
+        W[1] = kblock<D>(c, j0, c1) - W[1];
+        if (p.has1) W[3] = kblock<D>(c, p.j1, c1) - W[3];
+    } else {
+        W[1] = -W[1];
+        W[3] = -W[3];
+    }
 }
 
-// ---------------------------------------------------------------------------------------------
-// phase 2: M = L^-1 by block columns (one wave per column, no inter-wave dependency) and
-//          alpha = M^T z accumulated as each M_ij is produced.
-// ---------------------------------------------------------------------------------------------
+// row r of a group: X = L_jr^-1 W_r, store, alpha update; r = 0 also folds row j0 into the row-j1 RHS.
+// `par` selects the LDS copy of the panel's factors (double-buffered across panels, see phase_pt).
 template <int D>
-__device__ __forceinline__ void phase_trtri(Ctx<D>& c) {
+__device__ __forceinline__ void pt_group_row(const Ctx<D>& c, const Panel<D>& p, int g, int r, int par, f32x16 (&W)[4]) {
     const int NB = c.NB, lane = c.lane;
-    for (int j0 = 0; j0 < NB; j0 += NW) {
-        // snake assignment balances the triangular column costs over the 4 waves
-        const int rnd = j0 / NW;
-        const int j = j0 + ((rnd & 1) ? (NW - 1 - c.w) : c.w);
-        if (j >= NB) continue;
-        const f32x16 Mjj = load_blk(c.Dinv + (size_t)j * BLK, lane);
-        float ap = 0.f;
+    const int jr = p.j0 + r;
+    const f32x16 Lop = ldl(c.L.LT + (2 * par + r) * BLK, lane);
+    f32x16 U01 = Lop;
+    const bool fold = (r == 0) && p.has1;
+    if (fold) U01 = ldl(c.L.U01 + par * BLK, lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ap = fmaf(Mjj[r], c.z[32 * j + rho(r, c.h)], ap);
-        for (int i = j + 1; i < NB; ++i) {
-            f32x16 acc = zero16();
-            {
-                f32x16 A = load_blk(c.U + (size_t)(j * NB + i) * BLK, lane);
-                mma_blk(acc, A, Mjj);
-            }
-            for (int k = j + 1; k < i; ++k) {
-                f32x16 A = load_blk(c.U + (size_t)(k * NB + i) * BLK, lane);
-                f32x16 B = load_blk(c.U + (size_t)(k * NB + j) * BLK, lane);   // M_kj (lower storage)
-                mma_blk(acc, A, B);
-            }
-            const f32x16 Lop = load_blk(c.DinvT + (size_t)i * BLK, lane);
-            f32x16 Mij = zero16();
-            mma_blk(Mij, Lop, acc);
-            Mij = -Mij;
-            store_blk(c.U + (size_t)(i * NB + j) * BLK, lane, Mij);
+    for (int n = 0; n < 2; ++n) {
+        const int e = 2 * g + n;
+        if (e < p.nItems) {
+            const bool isu = e < p.nU;
+            const int col = pt_item_col(p, e);
+            f32x16 src = W[n];
+            if (r == 1) src = W[2 + n];
+            f32x16 X = zero16();
+            mma_blk(X, Lop, src);
+            stg(c.ws, jr * NB + col, lane, X);          // U-type: upper slot (jr,col); M-type: lower slot
+            if (!isu) {
+                float ap = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ap = fmaf(Mij[r], c.z[32 * i + rho(r, c.h)], ap);
+                for (int q = 0; q < 16; ++q) ap = fmaf(X[q], lds_f[c.L.z + 32 * jr + rho(q, c.h)], ap);
+                ap = xhalf_sum(ap);
+                if (c.h == 0) lds_f[c.L.alpha + 32 * col + c.g] += ap;
+            }
+            if (fold) {
+                f32x16 T = zero16();
+                mma_blk(T, U01, X);
+                W[2 + n] -= T;
+            }
         }
-        const float a = xhalf_sum(ap);
-        if (c.h == 0) c.alpha[32 * j + c.g] = a;
+    }
+}
+
+// The diagonal chain of panel p (one wave): D00/D01/D11 accumulation over k < j0, the two 32x32
+// factorisations, U_j0j1, the forward solve z and M_j1,j0.  Publishes the factors in LDS copy `par`.
+// kwait: rows >= kwait of the panel columns are produced concurrently by another wave in this slot;
+// the chain polls sh->g0done (>= slot) before touching them.
+template <int D>
+__device__ __forceinline__ void pt_chain(Ctx<D>& c, const Panel<D>& p, const bool want_m, int par, int kwait, int slot) {
+    Shared* sh = shared_state();
+    const int NB = c.NB, lane = c.lane;
+    const int j0 = p.j0, j1 = p.j1;
+    const bool has1 = p.has1 != 0;
+    f32x16 D00 = zero16(), D01 = zero16(), D11 = zero16();
+    float tp0 = 0.f, tp1 = 0.f;
+    PROF_BEGIN();
+    // the chain is the critical path of the sweep: let it win VALU / LDS issue arbitration against the
+    // MFMA-bound wave of the other resident workgroup that shares this SIMD
+    __builtin_amdgcn_s_setprio(3);
+    for (int part = 0; part < 2; ++part) {
+        const int kb = part ? kwait : 0, ke = part ? j0 : kwait;
+        if (part == 1 && kwait < j0) {
+            // rows kwait.. of the panel columns come from group 0 of the previous panel (this slot)
+            while (__hip_atomic_load(&sh->g0done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < slot)
+                __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            PROF_END(c, 10);
+        }
+        if (kb < ke) {
+            f32x16 A0 = ldg(c.ws, kb * NB + j0, lane);
+            f32x16 A1 = ldg(c.ws, has1 ? kb * NB + j1 : c.zb, lane);
+            for (int k = kb; k < ke; ++k) {
+                f32x16 nA0 = A0, nA1 = A1;
+                if (k + 1 < ke) {
+                    nA0 = ldg(c.ws, (k + 1) * NB + j0, lane);
+                    nA1 = ldg(c.ws, has1 ? (k + 1) * NB + j1 : c.zb, lane);
+                }
+                mma_blk(D00, A0, A0);
+                mma_blk(D01, A0, A1);
+                mma_blk(D11, A1, A1);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float zk = lds_f[c.L.z + 32 * k + rho(q, c.h)];
+                    tp0 = fmaf(A0[q], zk, tp0);
+                    tp1 = fmaf(A1[q], zk, tp1);
+                }
+                A0 = nA0; A1 = nA1;
+            }
+        }
+    }
+    PROF_END(c, 0);
+    f32x16 S1keep = zero16();
+    const int nrow = has1 ? 2 : 1;
+    for (int r = 0; r < nrow; ++r) {
+        const int jr = j0 + r;
+        f32x16 Dd;
+        float tp;
+        if (r == 0) {
+            Dd = kblock<D>(c, j0, j0) - D00;
+            tp = tp0;
+        } else {
+            // D11 <- K_j1j1 - sum_{k<j0} .. - U01^T U01 ; t1 += U01^T z_j0
+            const f32x16 U01 = ldl(c.L.U01 + par * BLK, lane);
+            mma_blk(D11, U01, U01);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tp1 = fmaf(U01[q], lds_f[c.L.z + 32 * j0 + rho(q, c.h)], tp1);
+            Dd = kblock<D>(c, j1, j1) - D11;
+            tp = tp1;
+        }
+        f32x16 S1, S2;
+        double ls;
+        int bad;
+        PROF_END(c, 2);
+        diag_factor(Dd, c.L.Ad, c.L.piv, lane, S1, S2, ls, bad);
+        PROF_END(c, 1);
+        stg(c.ws, jr * NB + jr, lane, S1);            // M_jrjr
+        stg(c.ws, c.dT0 + jr, lane, S2);              // (L_jr^-1)^T
+        stl(c.L.LT + (2 * par + r) * BLK, lane, S2);
+        // z_jr = X (y_jr - t_jr): lane (h,g) holds X[g][rho(r,h)] in S2
+        const float t = xhalf_sum(tp);
+        if (c.h == 0) lds_f[c.L.tmp + c.g] = lds_f[c.L.y + 32 * jr + c.g] - t;
+        wave_lds_sync();
+        float zz = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) zz = fmaf(S2[q], lds_f[c.L.tmp + rho(q, c.h)], zz);
+        zz = xhalf_sum(zz);
+        if (c.h == 0) lds_f[c.L.z + 32 * jr + c.g] = zz;
+        if (lane == 0) { sh->logdet += ls; if (bad) sh->fail = 1; }
+        wave_lds_sync();
+        if (want_m) {
+            // alpha_jr += M_jrjr^T z_jr
+            float ap = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) ap = fmaf(S1[q], lds_f[c.L.z + 32 * jr + rho(q, c.h)], ap);
+            ap = xhalf_sum(ap);
+            if (c.h == 0) lds_f[c.L.alpha + 32 * jr + c.g] += ap;
+        }
+        if (r == 0) {
+            S1keep = S1;
+            if (has1) {
+                D01 = kblock<D>(c, j0, j1) - D01;
+                f32x16 U01 = zero16();
+                mma_blk(U01, S2, D01);
+                stg(c.ws, j0 * NB + j1, lane, U01);
+                stl(c.L.U01 + par * BLK, lane, U01);
+                wave_lds_sync();
+            }
+        } else if (want_m) {
+            // M_j1,j0 = -L_j1^-1 U01^T M_j0j0
+            const f32x16 U01 = ldl(c.L.U01 + par * BLK, lane);
+            f32x16 T = zero16();
+            mma_blk(T, U01, S1keep);
+            T = -T;
+            f32x16 Mx = zero16();
+            mma_blk(Mx, S2, T);
+            stg(c.ws, j1 * NB + j0, lane, Mx);
+            float ap = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) ap = fmaf(Mx[q], lds_f[c.L.z + 32 * j1 + rho(q, c.h)], ap);
+            ap = xhalf_sum(ap);
+            if (c.h == 0) lds_f[c.L.alpha + 32 * j0 + c.g] += ap;
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    PROF_END(c, 2);
+}
+
+template <int D>
+__device__ __forceinline__ Panel<D> make_panel(int NB, int pi, bool want_m) {
+    Panel<D> p;
+    p.j0 = 2 * pi;
+    p.j1 = p.j0 + 1;
+    p.has1 = (p.j1 < NB) ? 1 : 0;
+    p.nU = p.has1 ? (NB - 1 - p.j1) : 0;
+    p.nItems = p.nU + (want_m ? p.j0 : 0);
+    return p;
+}
+
+// Software-pipelined sweep with ONE workgroup barrier per panel: in slot s wave 0 runs the diagonal
+// chain of panel s while waves 1..3 run the bulk groups of panel s-1 (whose factors were published in
+// slot s-1).  The only intra-slot dependency -- the chain needs rows j0(s-1), j1(s-1) of its two panel
+// columns, i.e. group 0 of panel s-1 -- is signalled through an LDS flag.  The 32x32 factorisations
+// (a long dependent chain) therefore overlap the MFMA-bound group work instead of stalling it.
+template <int D>
+__device__ __forceinline__ void phase_pt(Ctx<D>& c, const bool want_m) {
+    Shared* sh = shared_state();
+    const int NB = c.NB, w = c.w;
+    const int NP = (NB + 1) >> 1;
+    if (c.tid == 0) { sh->logdet = 0.0; sh->fail = 0; sh->g0done = 0; sh->gnext[0] = 0; sh->gnext[1] = (NP > 1) ? 1 : 0; sh->gradnext = 0; }
+    for (int idx = c.tid; idx < c.Npad; idx += NT) lds_f[c.L.alpha + idx] = 0.f;
+    __syncthreads();
+    for (int s = 0; s <= NP; ++s) {
+        const bool chain_busy = s < NP;                 // wave 0 runs the chain of panel s first
+        if (chain_busy && w == 0) {
+            // queue head of the NEXT slot: group 0 is reserved for wave 1 while a chain is running
+            if (c.lane == 0) sh->gnext[(s + 1) & 1] = (s + 1 < NP) ? 1 : 0;
+            Panel<D> p = make_panel<D>(NB, s, want_m);
+            const int kwait = (s > 0) ? (p.j0 - 2) : p.j0;
+            pt_chain<D>(c, p, want_m, s & 1, kwait, s);
+        }
+        PROF_BEGIN();
+        if (s >= 1) {
+            const Panel<D> q = make_panel<D>(NB, s - 1, want_m);
+            const int nGroups = (q.nItems + 1) >> 1;
+            const int par = (s - 1) & 1;
+            f32x16 W[4];
+            // wave 1 starts with group 0 (the chain of this slot waits for it); everything else is pulled
+            // from the slot's queue, so wave 0 joins as soon as its chain is done
+            int g = (chain_busy && w == 1) ? 0 : wave_pull(&sh->gnext[s & 1], c.lane);
+            while (g < nGroups) {
+                pt_group_kloop<D>(c, q, g, W);
+                PROF_END(c, 4);
+                pt_group_row<D>(c, q, g, 0, par, W);
+                if (q.has1) pt_group_row<D>(c, q, g, 1, par, W);
+                if (g == 0 && chain_busy) {
+                    // rows j0(s-1), j1(s-1) of the next panel's columns are in memory: release the chain
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (c.lane == 0) __hip_atomic_store(&sh->g0done, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                PROF_END(c, 5);
+                g = wave_pull(&sh->gnext[s & 1], c.lane);
+            }
+        }
+        __syncthreads();
+        PROF_END(c, 3);
+        if (sh->fail) break;
     }
     __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
-// phase 3: (K^-1)_ab = sum_{c>=a} M_ca^T M_cb, contracted in registers with dK/dtheta.
-// Writes sh->gth (dNLL/dtheta).
+// phase G: (K^-1)_ab = sum_{c>=a} M_ca^T M_cb for a >= b, by groups of 2 block rows x 2 block columns
+// per wave (4 accumulators, double-buffered operand registers), contracted in registers against
+// dK/dtheta recomputed on the fly (K^-1 is never stored).  Writes sh->gth (dNLL/dtheta).
 // ---------------------------------------------------------------------------------------------
 template <int D>
 __device__ __forceinline__ void phase_grad(Ctx<D>& c) {
-    Shared* sh = c.sh;
+    Shared* sh = shared_state();
     const int NB = c.NB, lane = c.lane;
     float accl[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) accl[d] = 0.f;
     float accsf = 0.f, accsn = 0.f;
-    int pair = 0;
-    for (int a = 0; a < NB; ++a) {
-        for (int b = 0; b <= a; ++b, ++pair) {
-            if ((pair & (NW - 1)) != c.w) continue;
-            f32x16 acc = zero16();
-            if (a == b) {
-                f32x16 A = load_blk(c.Dinv + (size_t)a * BLK, lane);
-                mma_blk(acc, A, A);
-                for (int cc = a + 1; cc < NB; ++cc) {
-                    f32x16 A2 = load_blk(c.U + (size_t)(cc * NB + a) * BLK, lane);
-                    mma_blk(acc, A2, A2);
+    // groups (a-pair, b-pair) are dealt round-robin (static => the summation order, hence the result, is
+    // reproducible bit for bit); consecutive groups share the a-pair, so the A blocks hit L1/L2
+    int gidx = 0;
+    for (int a0 = 0; a0 < NB; a0 += 2) {
+        const int a1 = a0 + 1;
+        const bool hasa1 = a1 < NB;
+        const int bmax = hasa1 ? a1 : a0;
+        for (int b0 = 0; b0 <= bmax; b0 += 2, ++gidx) {
+            if ((gidx & (NW - 1)) != c.w) continue;
+            PROF_BEGIN();
+            const int b1 = b0 + 1;
+            const bool hasb1 = b1 <= bmax;
+            f32x16 acc[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n] = zero16();
+            // M_cc,x lives at block cc*NB + x (cc >= x); operands out of range point at the zero block
+            f32x16 A0 = ldg(c.ws, a0 * NB + a0, lane);
+            f32x16 A1 = ldg(c.ws, c.zb, lane);
+            f32x16 B0 = ldg(c.ws, a0 * NB + b0, lane);
+            f32x16 B1 = ldg(c.ws, (hasb1 && b1 <= a0) ? a0 * NB + b1 : c.zb, lane);
+            for (int cc = a0; cc < NB; ++cc) {
+                f32x16 nA0 = A0, nA1 = A1, nB0 = B0, nB1 = B1;
+                if (cc + 1 < NB) {
+                    const int cn = cc + 1;
+                    nA0 = ldg(c.ws, cn * NB + a0, lane);
+                    nA1 = ldg(c.ws, hasa1 ? cn * NB + a1 : c.zb, lane);        // cn >= a1 always
+                    nB0 = ldg(c.ws, cn * NB + b0, lane);
+                    nB1 = ldg(c.ws, hasb1 ? cn * NB + b1 : c.zb, lane);        // b1 <= a1 <= cn
                 }
-            } else {
-                {
-                    f32x16 A = load_blk(c.Dinv + (size_t)a * BLK, lane);
-                    f32x16 B = load_blk(c.U + (size_t)(a * NB + b) * BLK, lane);
-                    mma_blk(acc, A, B);
-                }
-                for (int cc = a + 1; cc < NB; ++cc) {
-                    f32x16 A = load_blk(c.U + (size_t)(cc * NB + a) * BLK, lane);
-                    f32x16 B = load_blk(c.U + (size_t)(cc * NB + b) * BLK, lane);
-                    mma_blk(acc, A, B);
-                }
+                mma_blk(acc[0], A0, B0);
+                mma_blk(acc[1], A0, B1);
+                mma_blk(acc[2], A1, B0);
+                mma_blk(acc[3], A1, B1);
+                A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
             }
-            contract<D>(c, acc, a, b, (a == b) ? 1.f : 2.f, accl, accsf, accsn);
+            PROF_END(c, 6);
+            contract<D>(c, acc[0], a0, b0, (a0 == b0) ? 1.f : 2.f, accl, accsf, accsn);
+            if (hasb1 && b1 <= a0) contract<D>(c, acc[1], a0, b1, (a0 == b1) ? 1.f : 2.f, accl, accsf, accsn);
+            if (hasa1) {
+                contract<D>(c, acc[2], a1, b0, (a1 == b0) ? 1.f : 2.f, accl, accsf, accsn);
+                if (hasb1) contract<D>(c, acc[3], a1, b1, (a1 == b1) ? 1.f : 2.f, accl, accsf, accsn);
+            }
+            PROF_END(c, 7);
         }
     }
     // wave reduction (doubles), then across waves through LDS
@@ -551,19 +822,18 @@ __device__ __forceinline__ void phase_grad(Ctx<D>& c) {
 #pragma unroll
         for (int i = 0; i < D + 2; ++i) sh->red[c.w][i] = v[i];
     }
-    __syncthreads();
+    {
+        PROF_BEGIN();
+        __syncthreads();
+        PROF_END(c, 8);
+    }
     if (c.tid == 0) {
         for (int i = 0; i < D + 2; ++i) {
             double s = 0.0;
             for (int ww = 0; ww < NW; ++ww) s += sh->red[ww][i];
-            if (i < D) {
-                // scaled diff^2 already carries 1/l^2; dk/dl = g * diff^2 / l^3
-                sh->gth[i] = 0.5 * (double)c.sf2 * s / sh->theta[i];
-            } else if (i == D) {
-                sh->gth[i] = 0.5 * s;            // dK/dsf2 = kf (without sf2)
-            } else {
-                sh->gth[i] = 0.5 * s;
-            }
+            // scaled diff^2 already carries 1/l^2 (dk/dl = g diff^2 / l^3); kf, g are without sf2
+            if (i < D) sh->gth[i] = 0.5 * (double)c.sf2 * s / sh->theta[i];
+            else sh->gth[i] = 0.5 * s;
         }
     }
     __syncthreads();
@@ -572,9 +842,9 @@ __device__ __forceinline__ void phase_grad(Ctx<D>& c) {
 // quadratic form + assemble NLL (all threads)
 template <int D>
 __device__ __forceinline__ void finish_nll(Ctx<D>& c) {
-    Shared* sh = c.sh;
+    Shared* sh = shared_state();
     double q = 0.0;
-    for (int p = c.tid; p < c.N; p += NT) { const double zz = (double)c.z[p]; q += zz * zz; }
+    for (int p = c.tid; p < c.N; p += NT) { const double zz = (double)lds_f[c.L.z + p]; q += zz * zz; }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
     if (c.lane == 0) sh->red[c.w][7] = q;
@@ -590,8 +860,9 @@ __device__ __forceinline__ void finish_nll(Ctx<D>& c) {
 // one objective (+ gradient) evaluation at sh->theta.  On return sh->nll, sh->gth, sh->fail are set.
 template <int D>
 __device__ __forceinline__ void evaluate(Ctx<D>& c, bool want_grad) {
-    Shared* sh = c.sh;
+    Shared* sh = shared_state();
     __syncthreads();
+    PROF_BEGIN();
     float invl[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) invl[d] = (float)(1.0 / sh->theta[d]);
@@ -599,70 +870,92 @@ __device__ __forceinline__ void evaluate(Ctx<D>& c, bool want_grad) {
     c.sn2 = (float)sh->theta[D + 1];
     for (int idx = c.tid; idx < c.Npad; idx += NT) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) c.xsc[d * c.Npad + idx] = c.xs[d * c.Npad + idx] * invl[d];
+        for (int d = 0; d < D; ++d) lds_f[c.L.xsc + d * c.Npad + idx] = lds_f[c.L.xs + d * c.Npad + idx] * invl[d];
     }
     __syncthreads();
-    phase_potrf<D>(c);
+    phase_pt<D>(c, want_grad);
     if (sh->fail) {
         if (c.tid == 0) { sh->nll = __builtin_inf(); for (int i = 0; i < D + 2; ++i) sh->gth[i] = 0.0; }
         __syncthreads();
         return;
     }
     finish_nll<D>(c);
-    if (want_grad) {
-        phase_trtri<D>(c);
-        phase_grad<D>(c);
-    }
+    if (want_grad) phase_grad<D>(c);
     if (c.tid == 0) {
         sh->n_eval += 1;
         if (!(sh->nll == sh->nll)) sh->fail = 1;
     }
     __syncthreads();
+    PROF_END(c, 9);
 }
 
 // ---------------------------------------------------------------------------------------------
-// prediction: V = L^-1 K_* by 32-column chunks (one wave per chunk), f* = V^T z,
-// f*_var = sf2 - colsum(V^2), y_var = f*_var + sn2   (GPSat/models/gpflow_models.py:229-243)
-// Requires U, DinvT, z of a successful phase_potrf at the final parameters.
+// prediction: V = L^-1 K_* by pairs of 32-column chunks per wave (2 accumulators, double-buffered
+// operands), f* = V^T z, f*_var = sf2 - colsum(V^2), y_var = f*_var + sn2
+// (GPSat/models/gpflow_models.py:229-243).  Requires U, DinvT, z of a successful phase_pt at the final
+// parameters.
 // ---------------------------------------------------------------------------------------------
 template <int D>
 __device__ __forceinline__ void predict_tile(Ctx<D>& c, const float* __restrict__ Xs, float* __restrict__ fm,
-                             float* __restrict__ fv, float* __restrict__ yv, const float (&invl)[D]) {
+                                             float* __restrict__ fv, float* __restrict__ yv, const float (&invl)[D]) {
     const int NB = c.NB, lane = c.lane;
     const int PC = (c.P + 31) / 32;
-    float* Vw = c.Vs + (size_t)c.w * NB * BLK;
-    for (int pc = c.w; pc < PC; pc += NW) {
-        const int q = 32 * pc + c.g;
-        const bool qv = q < c.P;
-        float xq[D];
+    const int v0 = c.vs0 + c.w * 2 * NB;          // this wave's V scratch: [2][NB] blocks
+    for (int pc = 2 * c.w; pc < PC; pc += 2 * NW) {
+        const int qa = 32 * pc + c.g, qb = qa + 32;
+        const bool va = qa < c.P, vb = qb < c.P;
+        float xa[D], xb[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) xq[d] = qv ? Xs[(size_t)q * D + d] * invl[d] : 0.f;
-        float vs = 0.f, ms = 0.f;
+        for (int d = 0; d < D; ++d) {
+            xa[d] = va ? Xs[(size_t)qa * D + d] * invl[d] : 0.f;
+            xb[d] = vb ? Xs[(size_t)qb * D + d] * invl[d] : 0.f;
+        }
+        float vsa = 0.f, msa = 0.f, vsb = 0.f, msb = 0.f;
         for (int j = 0; j < NB; ++j) {
-            f32x16 acc = zero16();
-            for (int k = 0; k < j; ++k) {
-                f32x16 A = load_blk(c.U + (size_t)(k * NB + j) * BLK, lane);
-                f32x16 B = load_blk(Vw + (size_t)k * BLK, lane);
-                mma_blk(acc, A, B);
+            f32x16 acc0 = zero16(), acc1 = zero16();
+            if (j > 0) {
+                f32x16 A = ldg(c.ws, j, lane);                 // U_0,j
+                f32x16 B0 = ldg(c.ws, v0, lane);
+                f32x16 B1 = ldg(c.ws, v0 + NB, lane);
+                for (int k = 0; k < j; ++k) {
+                    f32x16 nA = A, nB0 = B0, nB1 = B1;
+                    if (k + 1 < j) {
+                        nA = ldg(c.ws, (k + 1) * NB + j, lane);
+                        nB0 = ldg(c.ws, v0 + k + 1, lane);
+                        nB1 = ldg(c.ws, v0 + NB + k + 1, lane);
+                    }
+                    mma_blk(acc0, A, B0);
+                    mma_blk(acc1, A, B1);
+                    A = nA; B0 = nB0; B1 = nB1;
+                }
             }
-            f32x16 Wb = ksblock<D>(c, j, xq, qv) - acc;
-            const f32x16 Lop = load_blk(c.DinvT + (size_t)j * BLK, lane);
-            f32x16 V = zero16();
-            mma_blk(V, Lop, Wb);
-            store_blk(Vw + (size_t)j * BLK, lane, V);
+            const f32x16 Lop = ldg(c.ws, c.dT0 + j, lane);
+            f32x16 Wa = ksblock<D>(c, j, xa, va) - acc0;
+            f32x16 Va = zero16();
+            mma_blk(Va, Lop, Wa);
+            stg(c.ws, v0 + j, lane, Va);
+            f32x16 Wb = ksblock<D>(c, j, xb, vb) - acc1;
+            f32x16 Vb = zero16();
+            mma_blk(Vb, Lop, Wb);
+            stg(c.ws, v0 + NB + j, lane, Vb);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                vs = fmaf(V[r], V[r], vs);
-                ms = fmaf(V[r], c.z[32 * j + rho(r, c.h)], ms);
+                const float zr = lds_f[c.L.z + 32 * j + rho(r, c.h)];
+                vsa = fmaf(Va[r], Va[r], vsa);
+                msa = fmaf(Va[r], zr, msa);
+                vsb = fmaf(Vb[r], Vb[r], vsb);
+                msb = fmaf(Vb[r], zr, msb);
             }
         }
-        vs = xhalf_sum(vs);
-        ms = xhalf_sum(ms);
-        if (c.h == 0 && qv) {
-            const float var = c.sf2 - vs;
-            fm[q] = ms;
-            fv[q] = var;
-            yv[q] = var + c.sn2;
+        vsa = xhalf_sum(vsa); msa = xhalf_sum(msa);
+        vsb = xhalf_sum(vsb); msb = xhalf_sum(msb);
+        if (c.h == 0 && va) {
+            const float var = c.sf2 - vsa;
+            fm[qa] = msa; fv[qa] = var; yv[qa] = var + c.sn2;
+        }
+        if (c.h == 0 && vb) {
+            const float var = c.sf2 - vsb;
+            fm[qb] = msb; fv[qb] = var; yv[qb] = var + c.sn2;
         }
     }
 }
@@ -935,7 +1228,6 @@ __device__ inline void opt_advance(Shared* sh, int H, const OptCfg& o) {
 // ---------------------------------------------------------------------------------------------
 template <int D>
 __global__ void __launch_bounds__(NT, 2) gp_tile_kernel(const KernelArgs A) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int H = D + 2;
     Ctx<D> c;
     c.tid = threadIdx.x;
@@ -945,19 +1237,26 @@ __global__ void __launch_bounds__(NT, 2) gp_tile_kernel(const KernelArgs A) {
     c.g = c.lane & 31;
     c.kern = A.kernel;
     const int NPmax = A.NBmax * 32;
-    Shared* sh = reinterpret_cast<Shared*>(smem);
-    c.sh = sh;
-    float* fp = reinterpret_cast<float*>(smem + ((sizeof(Shared) + 15) & ~size_t(15)));
-    c.xs = fp; fp += D * NPmax;
-    c.xsc = fp; fp += D * NPmax;
-    c.y = fp; fp += NPmax;
-    c.z = fp; fp += NPmax;
-    c.alpha = fp; fp += NPmax;
-    c.Ad = fp; fp += 32 * 33 + 3;   // 1059 floats; re-align below
-    fp = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(fp) + 15) & ~uintptr_t(15));
-    c.LinvT = fp; fp += BLK;
-    c.tmp = fp; fp += 32;
-    float* ws = A.ws + (size_t)blockIdx.x * A.ws_stride;
+    Shared* sh = shared_state();
+    int off = SHARED_FLOATS;
+    c.L.xs = off; off += D * NPmax;
+    c.L.xsc = off; off += D * NPmax;
+    c.L.y = off; off += NPmax;
+    c.L.z = off; off += NPmax;
+    c.L.alpha = off; off += NPmax;
+    c.L.LT = off; off += 4 * BLK;
+    c.L.U01 = off; off += 2 * BLK;
+    c.L.Ad = off; off += 32 * 33 + 3;       // 1059 -> keep the next offsets 16-B aligned
+    off = (off + 3) & ~3;
+    c.L.tmp = off; off += 32;
+    c.L.piv = off; off += 64;
+    c.ws = A.ws + (size_t)blockIdx.x * A.ws_stride;
+    c.zb = (int)(A.ws_stride / BLK) - 1;            // last block of the workgroup's workspace: zeros
+    for (int i = c.tid; i < BLK; i += NT) c.ws[(size_t)c.zb * BLK + i] = 0.f;
+    c.prof = sh->prof;
+#ifdef GPSAT_PROFILE
+    if (c.tid < NW * 16) sh->prof[c.tid] = 0ull;
+#endif
     OptCfg o;
     o.optimiser = A.optimiser; o.max_iter = A.max_iter; o.max_ls = A.max_ls; o.want_grad_out = A.grad != nullptr;
     o.ftol = A.ftol; o.gtol = A.gtol; o.adam_lr = A.adam_lr;
@@ -976,10 +1275,8 @@ __global__ void __launch_bounds__(NT, 2) gp_tile_kernel(const KernelArgs A) {
         c.NB = (c.N + 31) / 32;
         c.Npad = c.NB * 32;
         const int NB = c.NB;
-        c.U = ws;
-        c.Dinv = ws + (size_t)NB * NB * BLK;
-        c.DinvT = c.Dinv + (size_t)NB * BLK;
-        c.Vs = c.DinvT + (size_t)NB * BLK;
+        c.dT0 = NB * NB;
+        c.vs0 = c.dT0 + NB;
         if (c.N == 0) {
             if (c.tid == 0) {
                 A.status[t] = 4; A.n_eval[t] = 0; A.nll[t] = 0.0;
@@ -999,10 +1296,10 @@ __global__ void __launch_bounds__(NT, 2) gp_tile_kernel(const KernelArgs A) {
         for (int idx = c.tid; idx < c.Npad; idx += NT) {
             const bool v = idx < c.N;
 #pragma unroll
-            for (int d = 0; d < D; ++d) c.xs[d * c.Npad + idx] = v ? A.X[(size_t)(o0 + idx) * D + d] : 0.f;
-            c.y[idx] = v ? A.y[o0 + idx] : 0.f;
-            c.z[idx] = 0.f;
-            c.alpha[idx] = 0.f;
+            for (int d = 0; d < D; ++d) lds_f[c.L.xs + d * c.Npad + idx] = v ? A.X[(size_t)(o0 + idx) * D + d] : 0.f;
+            lds_f[c.L.y + idx] = v ? A.y[o0 + idx] : 0.f;
+            lds_f[c.L.z + idx] = 0.f;
+            lds_f[c.L.alpha + idx] = 0.f;
         }
         if (c.tid == 0) {
             sh->n_eval = 0; sh->n_eval_opt = 0; sh->status = 5; sh->iter = 0; sh->hist_n = 0; sh->hist_pos = 0;
@@ -1057,18 +1354,21 @@ __global__ void __launch_bounds__(NT, 2) gp_tile_kernel(const KernelArgs A) {
             }
         }
     }
+#ifdef GPSAT_PROFILE
+    __syncthreads();
+    if (A.prof && c.tid < NW * 16) atomicAdd(&A.prof[c.tid], sh->prof[c.tid]);
+#endif
 }
 
 size_t shared_bytes(int D, int NBmax) {
-    size_t s = (sizeof(Shared) + 15) & ~size_t(15);
     const size_t NP = (size_t)NBmax * 32;
-    s += sizeof(float) * (2 * D * NP + 3 * NP + 32 * 33 + 3 + 4 + BLK + 32);
-    return (s + 15) & ~size_t(15);
+    size_t fl = (size_t)SHARED_FLOATS + 2 * D * NP + 3 * NP + 6 * BLK + 32 * 33 + 3 + 4 + 32 + 64;
+    return (fl * sizeof(float) + 15) & ~size_t(15);
 }
 
 size_t workspace_floats_per_wg(int NBmax) {
-    // U/M square + Dinv + DinvT + per-wave V scratch
-    return (size_t)BLK * ((size_t)NBmax * NBmax + 2 * (size_t)NBmax + (size_t)NW * NBmax);
+    // U/M square + DinvT + per-wave V scratch (2 chunks) + one block of zeros
+    return (size_t)BLK * ((size_t)NBmax * NBmax + (size_t)NBmax + (size_t)NW * 2 * NBmax + 1);
 }
 
 hipError_t launch_tiles(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream) {
