@@ -218,9 +218,9 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
 
     gpsat::KernelArgs a;
     a.T = T; a.kernel = b->kernel; a.optimiser = b->optimiser; a.max_iter = b->max_iter;
-    a.max_ls = b->max_ls > 0 ? b->max_ls : 20;
+    a.max_ls = b->max_ls > 0 ? b->max_ls : 10;
     a.NBmax = NBmax;
-    a.ftol = b->ftol > 0 ? b->ftol : 1e-7;
+    a.ftol = b->ftol > 0 ? b->ftol : 1e-6;
     a.gtol = b->gtol > 0 ? b->gtol : 1e-5;
     a.adam_lr = b->adam_lr > 0 ? b->adam_lr : 0.1;
     a.obs_off = d_i64; a.pred_off = d_i64 + (T + 1);

@@ -179,7 +179,7 @@ struct Shared {
     double S[MH][HMAX], Y[MH][HMAX], rho_[MH];
     double m1[HMAX], m2[HMAX];             // Adam moments
     // line search
-    double t, t_prev, f_prev, dphi_prev, t_lo, f_lo, dphi_lo, t_hi, f_hi, dphi_hi, dphi0, t_best, f_best;
+    double t, t_prev, f_prev, dphi_prev, t_lo, f_lo, dphi_lo, t_hi, f_hi, dphi_hi, dphi0, t_best, f_best, last_dec;
     int ls_phase, ls_iter, ls_done, ls_ok;
     int hist_n, hist_pos;
     int trainable[HMAX];
@@ -197,9 +197,9 @@ constexpr int SHARED_FLOATS = (int)((sizeof(Shared) + 15) / 16) * 4;
 __device__ __forceinline__ Shared* shared_state() { return reinterpret_cast<Shared*>(lds_f); }
 
 // float offsets into lds_f
-struct Lay { int xs, xsc, y, z, alpha, Ad, LT, U01, tmp, piv; };
+struct Lay { int xs, xsc, y, z, alpha, Ad, LT, U01, Wh, tmp, piv; };
 
-template <int D>
+template <int D, int KN>
 struct Ctx {
     Lay L;
     float* ws;                   // this workgroup's global workspace
@@ -207,7 +207,6 @@ struct Ctx {
     int N, NB, Npad, P;
     int tid, lane, w, h, g;
     float sf2, sn2;
-    int kern;
     unsigned long long* prof;    // LDS, [NW][16] (diagnostic build)
 };
 
@@ -217,7 +216,7 @@ struct Ctx {
 // the quadratic form and the gradient ("padding identity").
 // ---------------------------------------------------------------------------------------------
 template <int D, int KERN>
-__device__ __forceinline__ f32x16 kblock_t(const Ctx<D>& c, int bi, int bj) {
+__device__ __forceinline__ f32x16 kblock_t(const Ctx<D, KERN>& c, int bi, int bj) {
     const int q = 32 * bj + c.g;
     float xq[D];
 #pragma unroll
@@ -248,19 +247,14 @@ __device__ __forceinline__ f32x16 kblock_t(const Ctx<D>& c, int bi, int bj) {
     return out;
 }
 
-template <int D>
-__device__ __forceinline__ f32x16 kblock(const Ctx<D>& c, int bi, int bj) {
-    switch (c.kern) {
-        case 0: return kblock_t<D, 0>(c, bi, bj);
-        case 1: return kblock_t<D, 1>(c, bi, bj);
-        case 2: return kblock_t<D, 2>(c, bi, bj);
-        default: return kblock_t<D, 3>(c, bi, bj);
-    }
+template <int D, int KN>
+__device__ __forceinline__ f32x16 kblock(const Ctx<D, KN>& c, int bi, int bj) {
+    return kblock_t<D, KN>(c, bi, bj);
 }
 
 // cross-covariance block: rows = observations 32*bj.., cols = prediction points (xq scaled)
 template <int D, int KERN>
-__device__ __forceinline__ f32x16 ksblock_t(const Ctx<D>& c, int bj, const float (&xq)[D], bool qvalid) {
+__device__ __forceinline__ f32x16 ksblock_t(const Ctx<D, KERN>& c, int bj, const float (&xq)[D], bool qvalid) {
     f32x16 out;
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
@@ -282,14 +276,9 @@ __device__ __forceinline__ f32x16 ksblock_t(const Ctx<D>& c, int bj, const float
     return out;
 }
 
-template <int D>
-__device__ __forceinline__ f32x16 ksblock(const Ctx<D>& c, int bj, const float (&xq)[D], bool qvalid) {
-    switch (c.kern) {
-        case 0: return ksblock_t<D, 0>(c, bj, xq, qvalid);
-        case 1: return ksblock_t<D, 1>(c, bj, xq, qvalid);
-        case 2: return ksblock_t<D, 2>(c, bj, xq, qvalid);
-        default: return ksblock_t<D, 3>(c, bj, xq, qvalid);
-    }
+template <int D, int KN>
+__device__ __forceinline__ f32x16 ksblock(const Ctx<D, KN>& c, int bj, const float (&xq)[D], bool qvalid) {
+    return ksblock_t<D, KN>(c, bj, xq, qvalid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -297,7 +286,7 @@ __device__ __forceinline__ f32x16 ksblock(const Ctx<D>& c, int bj, const float (
 //   acc_l[d] += wgt * Q * g(r) * (scaled diff_d)^2 ; acc_sf += wgt * Q * kf ; acc_sn += Q on the diagonal
 // ---------------------------------------------------------------------------------------------
 template <int D, int KERN>
-__device__ __forceinline__ void contract_t(const Ctx<D>& c, const f32x16& kinv, int ba, int bb, float wgt,
+__device__ __forceinline__ void contract_t(const Ctx<D, KERN>& c, const f32x16& kinv, int ba, int bb, float wgt,
                                            float (&accl)[D], float& accsf, float& accsn) {
     const int q = 32 * bb + c.g;
     float xq[D];
@@ -342,15 +331,10 @@ __device__ __forceinline__ void contract_t(const Ctx<D>& c, const f32x16& kinv, 
     }
 }
 
-template <int D>
-__device__ __forceinline__ void contract(const Ctx<D>& c, const f32x16& kinv, int ba, int bb, float wgt,
+template <int D, int KN>
+__device__ __forceinline__ void contract(const Ctx<D, KN>& c, const f32x16& kinv, int ba, int bb, float wgt,
                                          float (&accl)[D], float& accsf, float& accsn) {
-    switch (c.kern) {
-        case 0: contract_t<D, 0>(c, kinv, ba, bb, wgt, accl, accsf, accsn); break;
-        case 1: contract_t<D, 1>(c, kinv, ba, bb, wgt, accl, accsf, accsn); break;
-        case 2: contract_t<D, 2>(c, kinv, ba, bb, wgt, accl, accsf, accsn); break;
-        default: contract_t<D, 3>(c, kinv, ba, bb, wgt, accl, accsf, accsn); break;
-    }
+    contract_t<D, KN>(c, kinv, ba, bb, wgt, accl, accsf, accsn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -378,6 +362,9 @@ __device__ __forceinline__ void diag_factor(const f32x16& W, int Ad, int piv, in
 #pragma unroll
     for (int r = 0; r < 16; ++r) lds_f[Ad + rho(r, h) * 33 + i] = W[r];
     wave_lds_sync();
+    // Sliding register window: at step s the logical register s+j lives in a[j], so the loop body does not
+    // depend on s and stays ROLLED (about 100 instructions that remain in the instruction cache; the
+    // unrolled form is 16 KiB of straight-line code that is re-fetched for every diagonal block).
     float a[32];
 #pragma unroll
     for (int q = 0; q < 16; ++q) a[q] = lds_f[Ad + i * 33 + 2 * q + h];        // W[i][2q+h]
@@ -385,13 +372,13 @@ __device__ __forceinline__ void diag_factor(const f32x16& W, int Ad, int piv, in
     for (int q = 0; q < 16; ++q) a[16 + q] = (2 * q + h == i) ? 1.f : 0.f;      // I[i][2q+h]
     int isbad = 0;
     float mp00 = 1.f, mp10 = 0.f, mp11 = 1.f;        // this lane's pivot block (rows i & ~1, i | 1)
-#pragma unroll
+#pragma nounroll
     for (int s = 0; s < 16; ++s) {
         const int k0 = 2 * s, k1 = k0 + 1;
-        // 2x2 pivot block: columns k0 (half 0) and k1 (half 1) live in register s
-        float p00 = readlane_f(a[s], k0);
-        float p10 = readlane_f(a[s], k1);
-        float p11 = readlane_f(a[s], k1 + 32);
+        // 2x2 pivot block: columns k0 (half 0) and k1 (half 1) live in the window's first register
+        float p00 = readlane_f(a[0], k0);
+        float p10 = readlane_f(a[0], k1);
+        float p11 = readlane_f(a[0], k1 + 32);
         float det = p00 * p11 - p10 * p10;
         if (!(p00 > 0.f) || !(det > 0.f)) { isbad = 1; p00 = 1.f; p10 = 0.f; p11 = 1.f; det = 1.f; }
         float rd = __builtin_amdgcn_rcpf(det);
@@ -402,38 +389,42 @@ __device__ __forceinline__ void diag_factor(const f32x16& W, int Ad, int piv, in
         mp10 = mine ? p10 : mp10;
         mp11 = mine ? p11 : mp11;
         // this row's entries in the two pivot columns, then [m0 m1] = [w0 w1] P^-1
-        const float other = lane_xor32(a[s], h);
-        const float w0 = h ? other : a[s];
-        const float w1 = h ? a[s] : other;
+        const float other = lane_xor32(a[0], h);
+        const float w0 = h ? other : a[0];
+        const float w1 = h ? a[0] : other;
         float m0 = (w0 * p11 - w1 * p10) * rd;
         float m1 = (w1 * p00 - w0 * p10) * rd;
         const bool below = i > k1;
         m0 = below ? m0 : 0.f;
         m1 = below ? m1 : 0.f;
-        // pivot rows (live registers s+1 .. s+16 of lanes k0, k1 in both halves) -> LDS -> everybody
+        // pivot rows (window registers 1..16 of lanes k0, k1 in both halves) -> LDS -> everybody
         if (mine) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) lds_f[piv + 32 * h + 16 * (i & 1) + t] = a[s + 1 + t];
+            for (int t = 0; t < 16; ++t) lds_f[piv + 32 * h + 16 * (i & 1) + t] = a[1 + t];
         }
         wave_lds_sync();
         float r0[16], r1[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) { r0[t] = lds_f[piv + 32 * h + t]; r1[t] = lds_f[piv + 32 * h + 16 + t]; }
+        // update the window and slide it by one register
 #pragma unroll
-        for (int t = 0; t < 16; ++t) a[s + 1 + t] = fmaf(-m1, r1[t], fmaf(-m0, r0[t], a[s + 1 + t]));
+        for (int t = 0; t < 16; ++t) a[t] = fmaf(-m1, r1[t], fmaf(-m0, r0[t], a[1 + t]));
+#pragma unroll
+        for (int t = 16; t < 31; ++t) a[t] = a[t + 1];
         wave_lds_sync();
     }
+    // after 16 slides a[0..15] hold the logical registers 16..31 = Lb^-1 (E part)
     // 2x2 Cholesky of this lane's pivot block: C = [[c00,0],[c10,c11]], C^-1 = [[1/c00,0],[-c10/(c00 c11),1/c11]]
     const float c00 = sqrtf(mp00);
     const float c10 = mp10 / c00;
     const float c11 = sqrtf(mp11 - c10 * c10);
     const float i00 = 1.0f / c00, i11 = 1.0f / c11;
     const float i10 = -c10 * i00 * i11;
-    // X row i: even row  -> i00 * E[i];  odd row -> i10 * E[i-1] + i11 * E[i]   (E = Lb^-1, lane i-1 via DPP row_shr:1)
+    // X row i: even row  -> i00 * E[i];  odd row -> i10 * E[i-1] + i11 * E[i]   (lane i-1 via DPP row_shr:1)
     const bool odd = (i & 1) != 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const float e = a[16 + q];
+        const float e = a[q];
         const float up = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(e), 0x111, 0xf, 0xf, true));
         const float x = odd ? fmaf(i10, up, i11 * e) : i00 * e;
         lds_f[Ad + i * 33 + 2 * q + h] = x;
@@ -476,8 +467,8 @@ __device__ __forceinline__ int pt_item_col(const Panel<D>& p, int e) { return (e
 
 // k-loop of the group holding items 2g, 2g+1: on return W[2r+n] is the finished right-hand side of
 // row jr, item n.
-template <int D>
-__device__ __forceinline__ void pt_group_kloop(const Ctx<D>& c, const Panel<D>& p, int g, f32x16 (&W)[4]) {
+template <int D, int KN>
+__device__ __forceinline__ void pt_group_kloop(const Ctx<D, KN>& c, const Panel<D>& p, int g, f32x16 (&W)[4]) {
     const int NB = c.NB, lane = c.lane, j0 = p.j0;
     const int e0 = 2 * g, e1 = e0 + 1;
     const bool v0 = e0 < p.nItems, v1 = e1 < p.nItems;
@@ -510,15 +501,15 @@ __device__ __forceinline__ void pt_group_kloop(const Ctx<D>& c, const Panel<D>& 
     }
     // U-type: W = K - acc ; M-type: W = -acc
     if (v0 && u0) {
-        W[0] = kblock<D>(c, j0, c0) - W[0];
-        if (p.has1) W[2] = kblock<D>(c, p.j1, c0) - W[2];
+        W[0] = kblock<D, KN>(c, j0, c0) - W[0];
+        if (p.has1) W[2] = kblock<D, KN>(c, p.j1, c0) - W[2];
     } else {
         W[0] = -W[0];
         W[2] = -W[2];
     }
     if (v1 && u1) {
-        W[1] = kblock<D>(c, j0, c1) - W[1];
-        if (p.has1) W[3] = kblock<D>(c, p.j1, c1) - W[3];
+        W[1] = kblock<D, KN>(c, j0, c1) - W[1];
+        if (p.has1) W[3] = kblock<D, KN>(c, p.j1, c1) - W[3];
     } else {
         W[1] = -W[1];
         W[3] = -W[3];
@@ -527,8 +518,8 @@ __device__ __forceinline__ void pt_group_kloop(const Ctx<D>& c, const Panel<D>& 
 
 // row r of a group: X = L_jr^-1 W_r, store, alpha update; r = 0 also folds row j0 into the row-j1 RHS.
 // `par` selects the LDS copy of the panel's factors (double-buffered across panels, see phase_pt).
-template <int D>
-__device__ __forceinline__ void pt_group_row(const Ctx<D>& c, const Panel<D>& p, int g, int r, int par, f32x16 (&W)[4]) {
+template <int D, int KN>
+__device__ __forceinline__ void pt_group_row(const Ctx<D, KN>& c, const Panel<D>& p, int g, int r, int par, f32x16 (&W)[4]) {
     const int NB = c.NB, lane = c.lane;
     const int jr = p.j0 + r;
     const f32x16 Lop = ldl(c.L.LT + (2 * par + r) * BLK, lane);
@@ -566,8 +557,8 @@ __device__ __forceinline__ void pt_group_row(const Ctx<D>& c, const Panel<D>& p,
 // factorisations, U_j0j1, the forward solve z and M_j1,j0.  Publishes the factors in LDS copy `par`.
 // kwait: rows >= kwait of the panel columns are produced concurrently by another wave in this slot;
 // the chain polls sh->g0done (>= slot) before touching them.
-template <int D>
-__device__ __forceinline__ void pt_chain(Ctx<D>& c, const Panel<D>& p, const bool want_m, int par, int kwait, int slot) {
+template <int D, int KN>
+__device__ __forceinline__ void pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const bool want_m, int par, int kwait, int slot) {
     Shared* sh = shared_state();
     const int NB = c.NB, lane = c.lane;
     const int j0 = p.j0, j1 = p.j1;
@@ -617,7 +608,7 @@ __device__ __forceinline__ void pt_chain(Ctx<D>& c, const Panel<D>& p, const boo
         f32x16 Dd;
         float tp;
         if (r == 0) {
-            Dd = kblock<D>(c, j0, j0) - D00;
+            Dd = kblock<D, KN>(c, j0, j0) - D00;
             tp = tp0;
         } else {
             // D11 <- K_j1j1 - sum_{k<j0} .. - U01^T U01 ; t1 += U01^T z_j0
@@ -625,7 +616,7 @@ __device__ __forceinline__ void pt_chain(Ctx<D>& c, const Panel<D>& p, const boo
             mma_blk(D11, U01, U01);
 #pragma unroll
             for (int q = 0; q < 16; ++q) tp1 = fmaf(U01[q], lds_f[c.L.z + 32 * j0 + rho(q, c.h)], tp1);
-            Dd = kblock<D>(c, j1, j1) - D11;
+            Dd = kblock<D, KN>(c, j1, j1) - D11;
             tp = tp1;
         }
         f32x16 S1, S2;
@@ -659,7 +650,7 @@ __device__ __forceinline__ void pt_chain(Ctx<D>& c, const Panel<D>& p, const boo
         if (r == 0) {
             S1keep = S1;
             if (has1) {
-                D01 = kblock<D>(c, j0, j1) - D01;
+                D01 = kblock<D, KN>(c, j0, j1) - D01;
                 f32x16 U01 = zero16();
                 mma_blk(U01, S2, D01);
                 stg(c.ws, j0 * NB + j1, lane, U01);
@@ -697,27 +688,31 @@ __device__ __forceinline__ Panel<D> make_panel(int NB, int pi, bool want_m) {
     return p;
 }
 
-// Software-pipelined sweep with ONE workgroup barrier per panel: in slot s wave 0 runs the diagonal
-// chain of panel s while waves 1..3 run the bulk groups of panel s-1 (whose factors were published in
-// slot s-1).  The only intra-slot dependency -- the chain needs rows j0(s-1), j1(s-1) of its two panel
-// columns, i.e. group 0 of panel s-1 -- is signalled through an LDS flag.  The 32x32 factorisations
-// (a long dependent chain) therefore overlap the MFMA-bound group work instead of stalling it.
-template <int D>
-__device__ __forceinline__ void phase_pt(Ctx<D>& c, const bool want_m) {
+// Software-pipelined sweep with ONE workgroup barrier per panel.  In slot s
+//   wave 0 ("chain")  : diagonal chain of panel s, then helps with the bulk;
+//   wave 1 ("column") : the two block columns the NEXT chain needs: rows of group 0 of panel s-1 (its
+//                       k-loop was already run in slot s-1 and is held in registers) -> flag for the chain,
+//                       then group 1 of panel s-1, then other bulk, finally the k-loop of group 0 of
+//                       panel s (held across the barrier);
+//   waves 2,3 ("bulk"): groups >= 2 of panel s-1, pulled from an LDS queue.
+// The dependent chain per panel is therefore only: 6 block products (rows of group 0) -> 2 k-steps + two
+// 32x32 factorisations; everything else overlaps it.
+template <int D, int KN>
+__device__ __forceinline__ void phase_pt(Ctx<D, KN>& c, const bool want_m) {
     Shared* sh = shared_state();
     const int NB = c.NB, w = c.w;
     const int NP = (NB + 1) >> 1;
-    if (c.tid == 0) { sh->logdet = 0.0; sh->fail = 0; sh->g0done = 0; sh->gnext[0] = 0; sh->gnext[1] = (NP > 1) ? 1 : 0; sh->gradnext = 0; }
+    if (c.tid == 0) { sh->logdet = 0.0; sh->fail = 0; sh->g0done = 0; sh->gnext[0] = 2; sh->gnext[1] = 2; }
     for (int idx = c.tid; idx < c.Npad; idx += NT) lds_f[c.L.alpha + idx] = 0.f;
     __syncthreads();
+    bool held = false;          // wave 1: LDS (L.Wh) holds the finished k-loop of group 0 of the current panel
     for (int s = 0; s <= NP; ++s) {
         const bool chain_busy = s < NP;                 // wave 0 runs the chain of panel s first
         if (chain_busy && w == 0) {
-            // queue head of the NEXT slot: group 0 is reserved for wave 1 while a chain is running
-            if (c.lane == 0) sh->gnext[(s + 1) & 1] = (s + 1 < NP) ? 1 : 0;
+            if (c.lane == 0) sh->gnext[(s + 1) & 1] = 2;     // queue head of the NEXT slot (groups 0,1: wave 1)
             Panel<D> p = make_panel<D>(NB, s, want_m);
             const int kwait = (s > 0) ? (p.j0 - 2) : p.j0;
-            pt_chain<D>(c, p, want_m, s & 1, kwait, s);
+            pt_chain<D, KN>(c, p, want_m, s & 1, kwait, s);
         }
         PROF_BEGIN();
         if (s >= 1) {
@@ -725,21 +720,53 @@ __device__ __forceinline__ void phase_pt(Ctx<D>& c, const bool want_m) {
             const int nGroups = (q.nItems + 1) >> 1;
             const int par = (s - 1) & 1;
             f32x16 W[4];
-            // wave 1 starts with group 0 (the chain of this slot waits for it); everything else is pulled
-            // from the slot's queue, so wave 0 joins as soon as its chain is done
-            int g = (chain_busy && w == 1) ? 0 : wave_pull(&sh->gnext[s & 1], c.lane);
-            while (g < nGroups) {
-                pt_group_kloop<D>(c, q, g, W);
-                PROF_END(c, 4);
-                pt_group_row<D>(c, q, g, 0, par, W);
-                if (q.has1) pt_group_row<D>(c, q, g, 1, par, W);
-                if (g == 0 && chain_busy) {
-                    // rows j0(s-1), j1(s-1) of the next panel's columns are in memory: release the chain
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    if (c.lane == 0) __hip_atomic_store(&sh->g0done, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (w == 1) {
+                if (nGroups > 0) {
+                    if (held) {
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) W[n] = ldl(c.L.Wh + n * BLK, c.lane);
+                    } else {
+                        pt_group_kloop<D, KN>(c, q, 0, W);
+                    }
+                    pt_group_row<D, KN>(c, q, 0, 0, par, W);
+                    if (q.has1) pt_group_row<D, KN>(c, q, 0, 1, par, W);
+                    if (chain_busy) {
+                        // rows j0(s-1), j1(s-1) of the chain's two columns are in memory: release the chain
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (c.lane == 0) __hip_atomic_store(&sh->g0done, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
+                held = false;
+                PROF_END(c, 5);
+                if (nGroups > 1) {
+                    pt_group_kloop<D, KN>(c, q, 1, W);
+                    PROF_END(c, 4);
+                    pt_group_row<D, KN>(c, q, 1, 0, par, W);
+                    if (q.has1) pt_group_row<D, KN>(c, q, 1, 1, par, W);
+                    PROF_END(c, 5);
+                }
+            }
+            int g = wave_pull(&sh->gnext[s & 1], c.lane);
+            while (g < nGroups) {
+                pt_group_kloop<D, KN>(c, q, g, W);
+                PROF_END(c, 4);
+                pt_group_row<D, KN>(c, q, g, 0, par, W);
+                if (q.has1) pt_group_row<D, KN>(c, q, g, 1, par, W);
                 PROF_END(c, 5);
                 g = wave_pull(&sh->gnext[s & 1], c.lane);
+            }
+        }
+        if (w == 1 && chain_busy) {
+            // run ahead: k-loop of group 0 of panel s (the columns of the next chain); it only needs rows
+            // < j0(s), all of which are in memory (the newest ones were written by this very wave)
+            const Panel<D> pn = make_panel<D>(NB, s, want_m);
+            if (pn.nU >= 1) {
+                f32x16 W[4];
+                pt_group_kloop<D, KN>(c, pn, 0, W);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) stl(c.L.Wh + n * BLK, c.lane, W[n]);
+                held = true;
+                PROF_END(c, 4);
             }
         }
         __syncthreads();
@@ -754,8 +781,8 @@ __device__ __forceinline__ void phase_pt(Ctx<D>& c, const bool want_m) {
 // per wave (4 accumulators, double-buffered operand registers), contracted in registers against
 // dK/dtheta recomputed on the fly (K^-1 is never stored).  Writes sh->gth (dNLL/dtheta).
 // ---------------------------------------------------------------------------------------------
-template <int D>
-__device__ __forceinline__ void phase_grad(Ctx<D>& c) {
+template <int D, int KN>
+__device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
     Shared* sh = shared_state();
     const int NB = c.NB, lane = c.lane;
     float accl[D];
@@ -798,11 +825,11 @@ __device__ __forceinline__ void phase_grad(Ctx<D>& c) {
                 A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
             }
             PROF_END(c, 6);
-            contract<D>(c, acc[0], a0, b0, (a0 == b0) ? 1.f : 2.f, accl, accsf, accsn);
-            if (hasb1 && b1 <= a0) contract<D>(c, acc[1], a0, b1, (a0 == b1) ? 1.f : 2.f, accl, accsf, accsn);
+            contract<D, KN>(c, acc[0], a0, b0, (a0 == b0) ? 1.f : 2.f, accl, accsf, accsn);
+            if (hasb1 && b1 <= a0) contract<D, KN>(c, acc[1], a0, b1, (a0 == b1) ? 1.f : 2.f, accl, accsf, accsn);
             if (hasa1) {
-                contract<D>(c, acc[2], a1, b0, (a1 == b0) ? 1.f : 2.f, accl, accsf, accsn);
-                if (hasb1) contract<D>(c, acc[3], a1, b1, (a1 == b1) ? 1.f : 2.f, accl, accsf, accsn);
+                contract<D, KN>(c, acc[2], a1, b0, (a1 == b0) ? 1.f : 2.f, accl, accsf, accsn);
+                if (hasb1) contract<D, KN>(c, acc[3], a1, b1, (a1 == b1) ? 1.f : 2.f, accl, accsf, accsn);
             }
             PROF_END(c, 7);
         }
@@ -840,8 +867,8 @@ __device__ __forceinline__ void phase_grad(Ctx<D>& c) {
 }
 
 // quadratic form + assemble NLL (all threads)
-template <int D>
-__device__ __forceinline__ void finish_nll(Ctx<D>& c) {
+template <int D, int KN>
+__device__ __forceinline__ void finish_nll(Ctx<D, KN>& c) {
     Shared* sh = shared_state();
     double q = 0.0;
     for (int p = c.tid; p < c.N; p += NT) { const double zz = (double)lds_f[c.L.z + p]; q += zz * zz; }
@@ -858,8 +885,8 @@ __device__ __forceinline__ void finish_nll(Ctx<D>& c) {
 }
 
 // one objective (+ gradient) evaluation at sh->theta.  On return sh->nll, sh->gth, sh->fail are set.
-template <int D>
-__device__ __forceinline__ void evaluate(Ctx<D>& c, bool want_grad) {
+template <int D, int KN>
+__device__ __forceinline__ void evaluate(Ctx<D, KN>& c, bool want_grad) {
     Shared* sh = shared_state();
     __syncthreads();
     PROF_BEGIN();
@@ -873,14 +900,14 @@ __device__ __forceinline__ void evaluate(Ctx<D>& c, bool want_grad) {
         for (int d = 0; d < D; ++d) lds_f[c.L.xsc + d * c.Npad + idx] = lds_f[c.L.xs + d * c.Npad + idx] * invl[d];
     }
     __syncthreads();
-    phase_pt<D>(c, want_grad);
+    phase_pt<D, KN>(c, want_grad);
     if (sh->fail) {
         if (c.tid == 0) { sh->nll = __builtin_inf(); for (int i = 0; i < D + 2; ++i) sh->gth[i] = 0.0; }
         __syncthreads();
         return;
     }
-    finish_nll<D>(c);
-    if (want_grad) phase_grad<D>(c);
+    finish_nll<D, KN>(c);
+    if (want_grad) phase_grad<D, KN>(c);
     if (c.tid == 0) {
         sh->n_eval += 1;
         if (!(sh->nll == sh->nll)) sh->fail = 1;
@@ -895,8 +922,8 @@ __device__ __forceinline__ void evaluate(Ctx<D>& c, bool want_grad) {
 // (GPSat/models/gpflow_models.py:229-243).  Requires U, DinvT, z of a successful phase_pt at the final
 // parameters.
 // ---------------------------------------------------------------------------------------------
-template <int D>
-__device__ __forceinline__ void predict_tile(Ctx<D>& c, const float* __restrict__ Xs, float* __restrict__ fm,
+template <int D, int KN>
+__device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const float* __restrict__ Xs, float* __restrict__ fm,
                                              float* __restrict__ fv, float* __restrict__ yv, const float (&invl)[D]) {
     const int NB = c.NB, lane = c.lane;
     const int PC = (c.P + 31) / 32;
@@ -930,11 +957,11 @@ __device__ __forceinline__ void predict_tile(Ctx<D>& c, const float* __restrict_
                 }
             }
             const f32x16 Lop = ldg(c.ws, c.dT0 + j, lane);
-            f32x16 Wa = ksblock<D>(c, j, xa, va) - acc0;
+            f32x16 Wa = ksblock<D, KN>(c, j, xa, va) - acc0;
             f32x16 Va = zero16();
             mma_blk(Va, Lop, Wa);
             stg(c.ws, v0 + j, lane, Va);
-            f32x16 Wb = ksblock<D>(c, j, xb, vb) - acc1;
+            f32x16 Wb = ksblock<D, KN>(c, j, xb, vb) - acc1;
             f32x16 Vb = zero16();
             mma_blk(Vb, Lop, Wb);
             stg(c.ws, v0 + NB + j, lane, Vb);
@@ -966,12 +993,12 @@ __device__ __forceinline__ void predict_tile(Ctx<D>& c, const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 __device__ inline double softplus_d(double x) { return log1p(exp(-fabs(x))) + fmax(x, 0.0); }
 
-__device__ inline double theta_of_u(const Shared* sh, int i, double u) {
+__device__ __noinline__ double theta_of_u(const Shared* sh, int i, double u) {
     if (sh->box[i]) return sh->lo[i] + (sh->hi[i] - sh->lo[i]) / (1.0 + exp(-u));
     return softplus_d(u) + sh->shift[i];
 }
 
-__device__ inline double u_of_theta(const Shared* sh, int i, double th) {
+__device__ __noinline__ double u_of_theta(const Shared* sh, int i, double th) {
     if (sh->box[i]) {
         const double lo = sh->lo[i], hi = sh->hi[i];
         double t = (th - lo) / (hi - lo);
@@ -991,7 +1018,7 @@ __device__ inline double dtheta_du(const Shared* sh, int i, double th) {
 }
 
 // thread 0: trial u -> theta for the next evaluation
-__device__ inline void set_trial(Shared* sh, int H, const double* u) {
+__device__ __noinline__ void set_trial(Shared* sh, int H, const double* u) {
     for (int i = 0; i < H; ++i) {
         sh->ut[i] = u[i];
         if (sh->trainable[i]) sh->theta[i] = theta_of_u(sh, i, u[i]);
@@ -999,14 +1026,14 @@ __device__ inline void set_trial(Shared* sh, int H, const double* u) {
 }
 
 // thread 0: after an evaluation, chain the gradient to u-space at the trial point
-__device__ inline void fetch_trial(Shared* sh, int H) {
+__device__ __noinline__ void fetch_trial(Shared* sh, int H) {
     sh->ft = sh->fail ? __builtin_inf() : sh->nll;
     for (int i = 0; i < H; ++i)
         sh->gt[i] = (sh->trainable[i] && !sh->fail) ? sh->gth[i] * dtheta_du(sh, i, sh->theta[i]) : 0.0;
 }
 
 // L-BFGS two-loop recursion (thread 0): d = -H g
-__device__ inline void lbfgs_direction(Shared* sh, int H) {
+__device__ __noinline__ void lbfgs_direction(Shared* sh, int H) {
     double q[HMAX], al[MH];
     for (int i = 0; i < H; ++i) q[i] = sh->g[i];
     const int n = sh->hist_n;
@@ -1051,7 +1078,7 @@ __device__ inline double cubic_min(double a, double fa, double da, double b, dou
 
 // strong-Wolfe line search step (thread 0).  Called after each trial evaluation.
 // Sets sh->ls_done (1 accepted / 2 failed) or the next sh->t.
-__device__ inline void ls_step(Shared* sh, int H, int max_ls) {
+__device__ __noinline__ void ls_step(Shared* sh, int H, int max_ls) {
     const double c1 = 1e-4, c2 = 0.9;
     const double t = sh->t, ft = sh->ft;
     double dphit = 0.0;
@@ -1105,7 +1132,7 @@ enum { PH_INIT = 0, PH_LS = 1, PH_ADAM = 2, PH_FINAL = 3, PH_EXIT = 4 };
 struct OptCfg { int optimiser, max_iter, max_ls, want_grad_out; double ftol, gtol, adam_lr; };
 
 // the accepted point is sh->u; decide whether the factorisation in memory already belongs to it
-__device__ inline void opt_finish(Shared* sh, int H, const OptCfg& o, bool factor_is_current) {
+__device__ __noinline__ void opt_finish(Shared* sh, int H, const OptCfg& o, bool factor_is_current) {
     sh->n_eval_opt = sh->n_eval;
     if (factor_is_current && !sh->fail) { sh->phase = PH_EXIT; return; }
     set_trial(sh, H, sh->u);
@@ -1113,7 +1140,7 @@ __device__ inline void opt_finish(Shared* sh, int H, const OptCfg& o, bool facto
     sh->phase = PH_FINAL;
 }
 
-__device__ inline void opt_start_iteration(Shared* sh, int H, const OptCfg& o) {
+__device__ __noinline__ void opt_start_iteration(Shared* sh, int H, const OptCfg& o) {
     if (o.optimiser == 2) {
         const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
         const int k = sh->iter + 1;
@@ -1148,7 +1175,7 @@ __device__ inline void opt_start_iteration(Shared* sh, int H, const OptCfg& o) {
     sh->phase = PH_LS;
 }
 
-__device__ inline void opt_advance(Shared* sh, int H, const OptCfg& o) {
+__device__ __noinline__ void opt_advance(Shared* sh, int H, const OptCfg& o) {
     switch (sh->phase) {
         case PH_INIT: {
             set_trial(sh, H, sh->u);
@@ -1198,6 +1225,7 @@ __device__ inline void opt_advance(Shared* sh, int H, const OptCfg& o) {
                 }
                 const double fold = sh->f, fnew = sh->ft;
                 sh->f = fnew;
+                sh->last_dec = fold - fnew;
                 for (int i = 0; i < H; ++i) { sh->u[i] = sh->ut[i]; sh->g[i] = sh->gt[i]; gmax = fmax(gmax, fabs(sh->gt[i])); }
                 sh->iter += 1;
                 const double den = fmax(fmax(fabs(fold), fabs(fnew)), 1.0);
@@ -1206,8 +1234,9 @@ __device__ inline void opt_advance(Shared* sh, int H, const OptCfg& o) {
                 opt_start_iteration(sh, H, o);
                 return;
             }
-            // line search failed: no further decrease is resolvable at this precision
-            if (sh->hist_n > 0 && sh->iter + 1 < o.max_iter) {
+            // line search failed: no further decrease is resolvable at this precision.  Restart from steepest
+            // descent only when the last accepted step still made real progress (far from the noise floor).
+            if (sh->hist_n > 0 && sh->iter + 1 < o.max_iter && sh->last_dec > 1e3 * o.ftol * fmax(fabs(sh->f), 1.0)) {
                 sh->hist_n = 0;           // one restart with steepest descent from the accepted point
                 sh->iter += 1;
                 opt_start_iteration(sh, H, o);
@@ -1226,16 +1255,15 @@ __device__ inline void opt_advance(Shared* sh, int H, const OptCfg& o) {
 // ---------------------------------------------------------------------------------------------
 // the persistent kernel
 // ---------------------------------------------------------------------------------------------
-template <int D>
+template <int D, int KN>
 __global__ void __launch_bounds__(NT, 2) gp_tile_kernel(const KernelArgs A) {
     constexpr int H = D + 2;
-    Ctx<D> c;
+    Ctx<D, KN> c;
     c.tid = threadIdx.x;
     c.lane = c.tid & 63;
     c.w = c.tid >> 6;
     c.h = c.lane >> 5;
     c.g = c.lane & 31;
-    c.kern = A.kernel;
     const int NPmax = A.NBmax * 32;
     Shared* sh = shared_state();
     int off = SHARED_FLOATS;
@@ -1246,6 +1274,7 @@ __global__ void __launch_bounds__(NT, 2) gp_tile_kernel(const KernelArgs A) {
     c.L.alpha = off; off += NPmax;
     c.L.LT = off; off += 4 * BLK;
     c.L.U01 = off; off += 2 * BLK;
+    c.L.Wh = off; off += 4 * BLK;          // column wave: finished k-loop of the next group 0, parked across the barrier
     c.L.Ad = off; off += 32 * 33 + 3;       // 1059 -> keep the next offsets 16-B aligned
     off = (off + 3) & ~3;
     c.L.tmp = off; off += 32;
@@ -1303,6 +1332,7 @@ __global__ void __launch_bounds__(NT, 2) gp_tile_kernel(const KernelArgs A) {
         }
         if (c.tid == 0) {
             sh->n_eval = 0; sh->n_eval_opt = 0; sh->status = 5; sh->iter = 0; sh->hist_n = 0; sh->hist_pos = 0;
+            sh->last_dec = 1e300;
             sh->fail = 0;
             for (int i = 0; i < H; ++i) {
                 const double lo = A.lo[(size_t)t * H + i], hi = A.hi[(size_t)t * H + i];
@@ -1323,7 +1353,7 @@ __global__ void __launch_bounds__(NT, 2) gp_tile_kernel(const KernelArgs A) {
 
         // ================= evaluate / advance loop (one inlined evaluate call site) =================
         for (;;) {
-            evaluate<D>(c, sh->want_grad != 0);
+            evaluate<D, KN>(c, sh->want_grad != 0);
             if (c.tid == 0) opt_advance(sh, H, o);
             __syncthreads();
             if (sh->phase == PH_EXIT) break;
@@ -1346,7 +1376,7 @@ __global__ void __launch_bounds__(NT, 2) gp_tile_kernel(const KernelArgs A) {
                 float invl[D];
 #pragma unroll
                 for (int d = 0; d < D; ++d) invl[d] = (float)(1.0 / sh->theta[d]);
-                predict_tile<D>(c, A.Xs + (size_t)p0 * D, A.f_mean + p0, A.f_var + p0, A.y_var + p0, invl);
+                predict_tile<D, KN>(c, A.Xs + (size_t)p0 * D, A.f_mean + p0, A.f_var + p0, A.y_var + p0, invl);
             } else {
                 for (long long q = p0 + c.tid; q < p1; q += NT) {
                     A.f_mean[q] = __builtin_nanf(""); A.f_var[q] = __builtin_nanf(""); A.y_var[q] = __builtin_nanf("");
@@ -1362,7 +1392,7 @@ __global__ void __launch_bounds__(NT, 2) gp_tile_kernel(const KernelArgs A) {
 
 size_t shared_bytes(int D, int NBmax) {
     const size_t NP = (size_t)NBmax * 32;
-    size_t fl = (size_t)SHARED_FLOATS + 2 * D * NP + 3 * NP + 6 * BLK + 32 * 33 + 3 + 4 + 32 + 64;
+    size_t fl = (size_t)SHARED_FLOATS + 2 * D * NP + 3 * NP + 10 * BLK + 32 * 33 + 3 + 4 + 32 + 64;
     return (fl * sizeof(float) + 15) & ~size_t(15);
 }
 
@@ -1371,24 +1401,35 @@ size_t workspace_floats_per_wg(int NBmax) {
     return (size_t)BLK * ((size_t)NBmax * NBmax + (size_t)NBmax + (size_t)NW * 2 * NBmax + 1);
 }
 
+template <int D, int KN>
+static hipError_t launch_one(const KernelArgs& a, int grid, size_t smem, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gp_tile_kernel<D, KN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((gp_tile_kernel<D, KN>), dim3(grid), dim3(NT), smem, stream, a);
+    return hipGetLastError();
+}
+
+template <int D>
+static hipError_t launch_d(const KernelArgs& a, int grid, size_t smem, hipStream_t stream) {
+    switch (a.kernel) {
+        case 0: return launch_one<D, 0>(a, grid, smem, stream);
+        case 1: return launch_one<D, 1>(a, grid, smem, stream);
+        case 2: return launch_one<D, 2>(a, grid, smem, stream);
+        case 3: return launch_one<D, 3>(a, grid, smem, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// one specialised kernel per (input dimension, covariance function): the covariance is inlined into the
+// K-block / contraction code, so specialising keeps each kernel's code (and its I-cache footprint) small
 hipError_t launch_tiles(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream) {
     switch (D) {
-        case 1:
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gp_tile_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            hipLaunchKernelGGL(gp_tile_kernel<1>, dim3(grid), dim3(NT), smem, stream, a);
-            break;
-        case 2:
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gp_tile_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            hipLaunchKernelGGL(gp_tile_kernel<2>, dim3(grid), dim3(NT), smem, stream, a);
-            break;
-        case 3:
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gp_tile_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            hipLaunchKernelGGL(gp_tile_kernel<3>, dim3(grid), dim3(NT), smem, stream, a);
-            break;
-        default:
-            return hipErrorInvalidValue;
+        case 1: return launch_d<1>(a, grid, smem, stream);
+        case 2: return launch_d<2>(a, grid, smem, stream);
+        case 3: return launch_d<3>(a, grid, smem, stream);
+        default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 }  // namespace gpsat

@@ -99,8 +99,9 @@ typedef struct gpsat_batch {
     int32_t memory;            /* GPSAT_MEM_HOST / GPSAT_MEM_DEVICE for the bulk arrays      */
     int32_t optimiser;         /* GPSAT_OPT_*                                               */
     int32_t max_iter;          /* optimiser iteration limit (scipy options.maxiter)         */
-    int32_t max_ls;            /* max line-search evaluations per iteration (0 = 20)        */
-    double  ftol;              /* relative objective decrease tolerance (0 = default 1e-7)  */
+    int32_t max_ls;            /* max line-search evaluations per iteration (0 = 10)        */
+    double  ftol;              /* relative objective decrease tolerance (0 = default 1e-6,   */
+                               /*   the fp32 analogue of SciPy's factr*eps = 2.2e-9 in fp64) */
     double  gtol;              /* max-norm gradient tolerance in u-space (0 = default 1e-5) */
     double  adam_lr;           /* Adam learning rate (0 = default 0.1)                      */
 
