@@ -39,6 +39,19 @@ def f_pred(N, P, D):
     return N * N * P + 2 * N * P + (3 * D + 6) * N * P / 2 + P * N
 
 
+def measured_traffic(a, T, N, P, D):
+    """HBM bytes per launch measured with rocprofv3 PMC passes (profiles/traffic.json), only when the
+    workload is the one it was measured on; otherwise null."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        w = t["workload"]
+        same = (w["tiles_per_gpu"], w["obs_per_tile"], w["pred_per_tile"], w["dim"], w["kernel"], w["optimiser"],
+                w["max_iter"]) == (T, N, P, D, a.kernel, a.optimiser, a.max_iter)
+        return float(t["hbm_bytes_per_launch"]) if same else None
+    except Exception:
+        return None
+
+
 def _gen_tile(args):
     from gpsat_amd import synthetic as syn
     seed, N, P, D, kid = args
@@ -197,8 +210,9 @@ def main():
                        "failed_tiles": int(np.sum(statuses >= 2)),
                        "parallelism": f"tile-sharded x{world}", "device": eng.device_name},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                         "kernel": "gp_tile_kernel<3>", "kernel_ms": round(k_ms, 3),
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         "traffic": measured_traffic(a, T, N, P, D),
+                         "kernel": f"gp_tile_kernel<{D}, {kid}>", "kernel_ms": round(k_ms, 3),
                          "flops_per_launch": flops_launch},
         }
         n_cpu_tiles = a.cpu_tiles if a.cpu_tiles >= 0 else (2 * workers if world == 1 else 0)
