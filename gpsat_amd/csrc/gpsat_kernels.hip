@@ -339,15 +339,18 @@ __device__ __forceinline__ void contract(const Ctx<D, KN>& c, const f32x16& kinv
 
 // ---------------------------------------------------------------------------------------------
 // 32x32 diagonal block: X with X W X^T = I ("L^-1"; only X and X^T are ever used, X need not be
-// triangular), one wave, all 64 lanes.
+// triangular), one wave.
 // Block Gaussian elimination with 2x2 pivots (W is SPD, no pivoting) of the augmented [W | I]:
-// W = Lb Db Lb^T, [W | I] -> [.. | Lb^-1], then X = Cb^-1 Lb^-1 with Db = Cb Cb^T (2x2 Cholesky per
-// pivot block).  Lane (i, h) owns row i and the augmented columns of parity h (32 registers).  At step
-// s the two pivot columns 2s, 2s+1 sit in register s of the two halves, the live window is registers
-// s+1..s+16 of every lane, and the two pivot rows are broadcast through a 64-float LDS buffer:
-// 16 dependent steps instead of 32 pivots + 32 triangular-inverse columns.
-// In : W (acc layout).  Out: S1 = X (acc layout), S2 = X^T (acc layout), logsum = -log|det X| (fp64),
-//      bad = 1 when a pivot block is not positive definite (or NaN).
+// W = Lb Db Lb^T, [W | I] -> [.. | Lb^-1], then X = Cb^-1 Lb^-1 with Db = Cb Cb^T (2x2 Cholesky per pivot
+// block).  Both 32x32 tiles stay in the MFMA accumulator layout and every elimination step is ONE rank-2
+// update per tile, issued as v_mfma_f32_32x32x2_f32:  T -= M[32x2] * R[2x32].
+//   * R (the two pivot rows) sits in registers r0, r0+1 of the half that owns rows 2s, 2s+1 -- already
+//     "column on lane", i.e. directly the B operand (the other half fetches it with one v_permlane32_swap);
+//   * M (the multipliers of every row) needs the two pivot COLUMNS; the trailing matrix is symmetric, so
+//     they equal the pivot rows and are again available per lane.
+// No LDS round trip, no cross-lane reduction inside the 16 dependent steps.
+// In : W (acc layout).  Out: S1 = X (acc layout), S2 = X^T (acc layout, one transposition through the LDS
+//      scratch Ad), logsum = -log|det X| (fp64), bad = 1 when a pivot block is not positive definite (or NaN).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float lane_xor32(float x, int h) {
     // value of lane ^ 32 (v_permlane32_swap: VALU, no LDS round trip)
@@ -358,88 +361,87 @@ __device__ __forceinline__ float lane_xor32(float x, int h) {
 
 __device__ __forceinline__ void diag_factor(const f32x16& W, int Ad, int piv, int lane, f32x16& S1, f32x16& S2,
                                             double& logsum, int& bad) {
-    const int h = lane >> 5, i = lane & 31;
+    const int h = lane >> 5, g = lane & 31;
+    f32x16 TA = W;
+    f32x16 TE;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) lds_f[Ad + rho(r, h) * 33 + i] = W[r];
-    wave_lds_sync();
-    // Sliding register window: at step s the logical register s+j lives in a[j], so the loop body does not
-    // depend on s and stays ROLLED (about 100 instructions that remain in the instruction cache; the
-    // unrolled form is 16 KiB of straight-line code that is re-fetched for every diagonal block).
-    float a[32];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) a[q] = lds_f[Ad + i * 33 + 2 * q + h];        // W[i][2q+h]
-#pragma unroll
-    for (int q = 0; q < 16; ++q) a[16 + q] = (2 * q + h == i) ? 1.f : 0.f;      // I[i][2q+h]
+    for (int r = 0; r < 16; ++r) TE[r] = (rho(r, h) == g) ? 1.f : 0.f;
     int isbad = 0;
-    float mp00 = 1.f, mp10 = 0.f, mp11 = 1.f;        // this lane's pivot block (rows i & ~1, i | 1)
-#pragma nounroll
+    float q00 = 1.f, q10 = 0.f, q11 = 1.f;            // lane s (< 16) keeps pivot block s
+    // 16 dependent steps; the critical chain per step is MFMA -> 3 readlanes -> det, rcp -> multipliers -> MFMA.
+    // Everything that is not on it (2x2 Cholesky, scaling of the finished rows, log) is done once afterwards.
+#pragma unroll
     for (int s = 0; s < 16; ++s) {
         const int k0 = 2 * s, k1 = k0 + 1;
-        // 2x2 pivot block: columns k0 (half 0) and k1 (half 1) live in the window's first register
-        float p00 = readlane_f(a[0], k0);
-        float p10 = readlane_f(a[0], k1);
-        float p11 = readlane_f(a[0], k1 + 32);
+        const int hp = (k0 >> 2) & 1;                 // half owning rows k0, k1
+        const int r0 = (k0 & 3) + 4 * (k0 >> 3);      // their registers: r0, r0 + 1
+        const int r1 = r0 + 1;
+        float p00 = readlane_f(TA[r0], 32 * hp + k0);
+        float p10 = readlane_f(TA[r1], 32 * hp + k0);
+        float p11 = readlane_f(TA[r1], 32 * hp + k1);
         float det = p00 * p11 - p10 * p10;
         if (!(p00 > 0.f) || !(det > 0.f)) { isbad = 1; p00 = 1.f; p10 = 0.f; p11 = 1.f; det = 1.f; }
         float rd = __builtin_amdgcn_rcpf(det);
         rd = rd * (2.f - det * rd);
-        rd = rd * (2.f - det * rd);
-        const bool mine = (i >> 1) == s;
-        mp00 = mine ? p00 : mp00;
-        mp10 = mine ? p10 : mp10;
-        mp11 = mine ? p11 : mp11;
-        // this row's entries in the two pivot columns, then [m0 m1] = [w0 w1] P^-1
-        const float other = lane_xor32(a[0], h);
-        const float w0 = h ? other : a[0];
-        const float w1 = h ? a[0] : other;
+        const bool mine = lane == s;
+        q00 = mine ? p00 : q00;
+        q10 = mine ? p10 : q10;
+        q11 = mine ? p11 : q11;
+        // pivot rows as seen by this lane's column g (own registers in half hp, swapped in otherwise)
+        const bool own = (h == hp);
+        const float a0 = TA[r0], a1 = TA[r1], e0 = TE[r0], e1 = TE[r1];
+        const float xa0 = lane_xor32(a0, h), xa1 = lane_xor32(a1, h);
+        const float xe0 = lane_xor32(e0, h), xe1 = lane_xor32(e1, h);
+        const float w0 = own ? a0 : xa0, w1 = own ? a1 : xa1;       // W'[k0][g], W'[k1][g]  (= W'[g][k0], W'[g][k1])
+        const float f0 = own ? e0 : xe0, f1 = own ? e1 : xe1;       // E[k0][g],  E[k1][g]
+        // multipliers of row g:  [m0 m1] = [w0 w1] P^-1, rows <= k1 are finished
         float m0 = (w0 * p11 - w1 * p10) * rd;
         float m1 = (w1 * p00 - w0 * p10) * rd;
-        const bool below = i > k1;
+        const bool below = g > k1;
         m0 = below ? m0 : 0.f;
         m1 = below ? m1 : 0.f;
-        // pivot rows (window registers 1..16 of lanes k0, k1 in both halves) -> LDS -> everybody
-        if (mine) {
-#pragma unroll
-            for (int t = 0; t < 16; ++t) lds_f[piv + 32 * h + 16 * (i & 1) + t] = a[1 + t];
-        }
-        wave_lds_sync();
-        float r0[16], r1[16];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) { r0[t] = lds_f[piv + 32 * h + t]; r1[t] = lds_f[piv + 32 * h + 16 + t]; }
-        // update the window and slide it by one register
-#pragma unroll
-        for (int t = 0; t < 16; ++t) a[t] = fmaf(-m1, r1[t], fmaf(-m0, r0[t], a[1 + t]));
-#pragma unroll
-        for (int t = 16; t < 31; ++t) a[t] = a[t + 1];
-        wave_lds_sync();
+        const float am = h ? -m1 : -m0;               // A operand: lane (h, i) supplies A[i][h]
+        const float bA = h ? w1 : w0;                 // B operand: lane (h, j) supplies R[h][j]
+        const float bE = h ? f1 : f0;
+        TA = __builtin_amdgcn_mfma_f32_32x32x2f32(am, bA, TA, 0, 0, 0);
+        TE = __builtin_amdgcn_mfma_f32_32x32x2f32(am, bE, TE, 0, 0, 0);
     }
-    // after 16 slides a[0..15] hold the logical registers 16..31 = Lb^-1 (E part)
-    // 2x2 Cholesky of this lane's pivot block: C = [[c00,0],[c10,c11]], C^-1 = [[1/c00,0],[-c10/(c00 c11),1/c11]]
-    const float c00 = sqrtf(mp00);
-    const float c10 = mp10 / c00;
-    const float c11 = sqrtf(mp11 - c10 * c10);
-    const float i00 = 1.0f / c00, i11 = 1.0f / c11;
-    const float i10 = -c10 * i00 * i11;
-    // X row i: even row  -> i00 * E[i];  odd row -> i10 * E[i-1] + i11 * E[i]   (lane i-1 via DPP row_shr:1)
-    const bool odd = (i & 1) != 0;
+    // TE = Lb^-1.  2x2 Cholesky of every pivot block in parallel (lane s owns block s):
+    // C = [[c00,0],[c10,c11]], C^-1 = [[1/c00,0],[-c10/(c00 c11),1/c11]]; coefficients -> LDS (piv) -> all lanes
+    {
+        const float c00 = sqrtf(q00);
+        const float c10 = q10 / c00;
+        const float c11 = sqrtf(q11 - c10 * c10);
+        const float i00 = 1.0f / c00, i11 = 1.0f / c11;
+        const float i10 = -c10 * i00 * i11;
+        if (lane < 16) {
+            lds_f[piv + lane] = i00;
+            lds_f[piv + 16 + lane] = i10;
+            lds_f[piv + 32 + lane] = i11;
+        }
+        // -log|det X| = sum log(c00 c11) over pivot blocks, fp64
+        double lg = (lane < 16) ? log((double)c00 * (double)c11) : 0.0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const float e = a[q];
-        const float up = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(e), 0x111, 0xf, 0xf, true));
-        const float x = odd ? fmaf(i10, up, i11 * e) : i00 * e;
-        lds_f[Ad + i * 33 + 2 * q + h] = x;
+        for (int off = 8; off >= 1; off >>= 1) lg += __shfl_xor(lg, off);
+        logsum = __shfl(lg, 0);
     }
     wave_lds_sync();
+    // X rows: even row k0 -> i00 * E[k0];  odd row k1 -> i10 * E[k0] + i11 * E[k1]; registers (2t, 2t+1) of a
+    // lane are the rows (k0, k1) of pivot block rho(2t, h) / 2
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        S1[r] = lds_f[Ad + rho(r, h) * 33 + i];     // X[rho][g]
-        S2[r] = lds_f[Ad + i * 33 + rho(r, h)];     // X^T in acc layout
+    for (int t = 0; t < 8; ++t) {
+        const int blk = rho(2 * t, h) >> 1;
+        const float i00 = lds_f[piv + blk], i10 = lds_f[piv + 16 + blk], i11 = lds_f[piv + 32 + blk];
+        const float e0 = TE[2 * t], e1 = TE[2 * t + 1];
+        S1[2 * t] = i00 * e0;
+        S1[2 * t + 1] = fmaf(i10, e0, i11 * e1);
     }
-    // -log|det X| = sum log(c00 c11) over pivot blocks, fp64; even lanes of half 0 own one block each
-    double lg = (h == 0 && !odd) ? log((double)c00 * (double)c11) : 0.0;
+    // X^T in acc layout: one transposition through LDS
 #pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) lg += __shfl_xor(lg, off);
-    logsum = __shfl(lg, 0);
+    for (int r = 0; r < 16; ++r) lds_f[Ad + rho(r, h) * 33 + g] = S1[r];
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S2[r] = lds_f[Ad + g * 33 + rho(r, h)];
     bad = isbad;
 }
 
@@ -746,7 +748,9 @@ __device__ __forceinline__ void phase_pt(Ctx<D, KN>& c, const bool want_m) {
                     PROF_END(c, 5);
                 }
             }
-            int g = wave_pull(&sh->gnext[s & 1], c.lane);
+            // the column wave already carries two groups' worth of fixed work per slot: while a chain is running
+            // it leaves the queue to the others
+            int g = (w == 1 && chain_busy) ? nGroups : wave_pull(&sh->gnext[s & 1], c.lane);
             while (g < nGroups) {
                 pt_group_kloop<D, KN>(c, q, g, W);
                 PROF_END(c, 4);
@@ -789,44 +793,59 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
 #pragma unroll
     for (int d = 0; d < D; ++d) accl[d] = 0.f;
     float accsf = 0.f, accsn = 0.f;
-    // groups (a-pair, b-pair) are dealt round-robin (static => the summation order, hence the result, is
-    // reproducible bit for bit); consecutive groups share the a-pair, so the A blocks hit L1/L2
+    // groups (a-pair, b-pair) are dealt to the waves in a fixed "snake" order over the cost-sorted list (cost =
+    // NB - a0 steps): static => the summation order, hence the result, is reproducible bit for bit, and the
+    // waves finish together; consecutive groups share the a-pair, so the A blocks hit L1/L2
     int gidx = 0;
     for (int a0 = 0; a0 < NB; a0 += 2) {
         const int a1 = a0 + 1;
         const bool hasa1 = a1 < NB;
         const int bmax = hasa1 ? a1 : a0;
         for (int b0 = 0; b0 <= bmax; b0 += 2, ++gidx) {
-            if ((gidx & (NW - 1)) != c.w) continue;
+            const int rnd = gidx / NW, pos = gidx % NW;
+            if (((rnd & 1) ? (NW - 1 - pos) : pos) != c.w) continue;
             PROF_BEGIN();
             const int b1 = b0 + 1;
             const bool hasb1 = b1 <= bmax;
+            const bool use01 = hasb1 && b1 <= a0;      // (a0, b1) is a lower block (false on the diagonal group)
             f32x16 acc[4];
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc[n] = zero16();
-            // M_cc,x lives at block cc*NB + x (cc >= x); operands out of range point at the zero block
+            // M_cc,x lives at block cc*NB + x (cc >= x).  First step cc = a0: only row a0 exists (M_a0,a1 = 0)
             f32x16 A0 = ldg(c.ws, a0 * NB + a0, lane);
-            f32x16 A1 = ldg(c.ws, c.zb, lane);
             f32x16 B0 = ldg(c.ws, a0 * NB + b0, lane);
-            f32x16 B1 = ldg(c.ws, (hasb1 && b1 <= a0) ? a0 * NB + b1 : c.zb, lane);
-            for (int cc = a0; cc < NB; ++cc) {
-                f32x16 nA0 = A0, nA1 = A1, nB0 = B0, nB1 = B1;
-                if (cc + 1 < NB) {
-                    const int cn = cc + 1;
-                    nA0 = ldg(c.ws, cn * NB + a0, lane);
-                    nA1 = ldg(c.ws, hasa1 ? cn * NB + a1 : c.zb, lane);        // cn >= a1 always
-                    nB0 = ldg(c.ws, cn * NB + b0, lane);
-                    nB1 = ldg(c.ws, hasb1 ? cn * NB + b1 : c.zb, lane);        // b1 <= a1 <= cn
-                }
+            f32x16 B1 = ldg(c.ws, use01 ? a0 * NB + b1 : c.zb, lane);
+            f32x16 A1 = A0;
+            if (a0 + 1 < NB) {
+                f32x16 nA0 = ldg(c.ws, a1 * NB + a0, lane);
+                f32x16 nA1 = ldg(c.ws, a1 * NB + a1, lane);
+                f32x16 nB0 = ldg(c.ws, a1 * NB + b0, lane);
+                f32x16 nB1 = ldg(c.ws, hasb1 ? a1 * NB + b1 : c.zb, lane);
                 mma_blk(acc[0], A0, B0);
-                mma_blk(acc[1], A0, B1);
-                mma_blk(acc[2], A1, B0);
-                mma_blk(acc[3], A1, B1);
+                if (use01) mma_blk(acc[1], A0, B1);
                 A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
+                for (int cc = a1; cc < NB; ++cc) {
+                    nA0 = A0; nA1 = A1; nB0 = B0; nB1 = B1;
+                    if (cc + 1 < NB) {
+                        const int cn = cc + 1;
+                        nA0 = ldg(c.ws, cn * NB + a0, lane);
+                        nA1 = ldg(c.ws, cn * NB + a1, lane);
+                        nB0 = ldg(c.ws, cn * NB + b0, lane);
+                        nB1 = ldg(c.ws, hasb1 ? cn * NB + b1 : c.zb, lane);
+                    }
+                    mma_blk(acc[0], A0, B0);
+                    if (use01) mma_blk(acc[1], A0, B1);
+                    mma_blk(acc[2], A1, B0);
+                    if (hasb1) mma_blk(acc[3], A1, B1);
+                    A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
+                }
+            } else {
+                mma_blk(acc[0], A0, B0);
+                if (use01) mma_blk(acc[1], A0, B1);
             }
             PROF_END(c, 6);
             contract<D, KN>(c, acc[0], a0, b0, (a0 == b0) ? 1.f : 2.f, accl, accsf, accsn);
-            if (hasb1 && b1 <= a0) contract<D, KN>(c, acc[1], a0, b1, (a0 == b1) ? 1.f : 2.f, accl, accsf, accsn);
+            if (use01) contract<D, KN>(c, acc[1], a0, b1, (a0 == b1) ? 1.f : 2.f, accl, accsf, accsn);
             if (hasa1) {
                 contract<D, KN>(c, acc[2], a1, b0, (a1 == b0) ? 1.f : 2.f, accl, accsf, accsn);
                 if (hasb1) contract<D, KN>(c, acc[3], a1, b1, (a1 == b1) ? 1.f : 2.f, accl, accsf, accsn);
