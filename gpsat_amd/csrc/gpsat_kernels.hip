@@ -555,12 +555,41 @@ __device__ __forceinline__ void pt_group_row(const Ctx<D, KN>& c, const Panel<D>
     }
 }
 
+// D00 += U_k,j0^T U_k,j0, D01 += U_k,j0^T U_k,j1, D11 += U_k,j1^T U_k,j1 and the forward-solve partials for k in [kb, ke)
+template <int D, int KN>
+__device__ __forceinline__ void chain_kloop(const Ctx<D, KN>& c, const Panel<D>& p, int kb, int ke, f32x16& D00, f32x16& D01,
+                                            f32x16& D11, float& tp0, float& tp1) {
+    const int NB = c.NB, lane = c.lane, j0 = p.j0, j1 = p.j1;
+    const bool has1 = p.has1 != 0;
+    if (kb >= ke) return;
+    f32x16 A0 = ldg(c.ws, kb * NB + j0, lane);
+    f32x16 A1 = ldg(c.ws, has1 ? kb * NB + j1 : c.zb, lane);
+    for (int k = kb; k < ke; ++k) {
+        f32x16 nA0 = A0, nA1 = A1;
+        if (k + 1 < ke) {
+            nA0 = ldg(c.ws, (k + 1) * NB + j0, lane);
+            nA1 = ldg(c.ws, has1 ? (k + 1) * NB + j1 : c.zb, lane);
+        }
+        mma_blk(D00, A0, A0);
+        mma_blk(D01, A0, A1);
+        mma_blk(D11, A1, A1);
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) {
+            const float zk = lds_f[c.L.z + 32 * k + rho(qq, c.h)];
+            tp0 = fmaf(A0[qq], zk, tp0);
+            tp1 = fmaf(A1[qq], zk, tp1);
+        }
+        A0 = nA0; A1 = nA1;
+    }
+}
+
 // The diagonal chain of panel p (one wave): D00/D01/D11 accumulation over k < j0, the two 32x32
 // factorisations, U_j0j1, the forward solve z and M_j1,j0.  Publishes the factors in LDS copy `par`.
 // kwait: rows >= kwait of the panel columns are produced concurrently by another wave in this slot;
 // the chain polls sh->g0done (>= slot) before touching them.
 template <int D, int KN>
-__device__ __forceinline__ void pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const bool want_m, int par, int kwait, int slot) {
+__device__ __forceinline__ void pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const Panel<D>& q, const bool want_m, int par,
+                                         int kwait, int slot, bool held) {
     Shared* sh = shared_state();
     const int NB = c.NB, lane = c.lane;
     const int j0 = p.j0, j1 = p.j1;
@@ -571,36 +600,50 @@ __device__ __forceinline__ void pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const
     // the chain is the critical path of the sweep: let it win VALU / LDS issue arbitration against the
     // MFMA-bound wave of the other resident workgroup that shares this SIMD
     __builtin_amdgcn_s_setprio(3);
-    for (int part = 0; part < 2; ++part) {
-        const int kb = part ? kwait : 0, ke = part ? j0 : kwait;
-        if (part == 1 && kwait < j0) {
-            // rows kwait.. of the panel columns come from group 0 of the previous panel (this slot)
-            while (__hip_atomic_load(&sh->g0done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < slot)
-                __builtin_amdgcn_s_sleep(2);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            PROF_END(c, 10);
-        }
-        if (kb < ke) {
-            f32x16 A0 = ldg(c.ws, kb * NB + j0, lane);
-            f32x16 A1 = ldg(c.ws, has1 ? kb * NB + j1 : c.zb, lane);
-            for (int k = kb; k < ke; ++k) {
-                f32x16 nA0 = A0, nA1 = A1;
-                if (k + 1 < ke) {
-                    nA0 = ldg(c.ws, (k + 1) * NB + j0, lane);
-                    nA1 = ldg(c.ws, has1 ? (k + 1) * NB + j1 : c.zb, lane);
-                }
-                mma_blk(D00, A0, A0);
-                mma_blk(D01, A0, A1);
-                mma_blk(D11, A1, A1);
+    chain_kloop<D, KN>(c, p, 0, kwait, D00, D01, D11, tp0, tp1);
+    if (kwait < j0 && !held) {
+        // group 0 of the previous panel is being finished by the column wave in this slot: wait for its rows
+        while (__hip_atomic_load(&sh->g0done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < slot)
+            __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        PROF_END(c, 10);
+        chain_kloop<D, KN>(c, p, kwait, j0, D00, D01, D11, tp0, tp1);
+    }
+    if (kwait < j0 && held) {
+        // Rows j0-2, j0-1 of this panel's two columns = group 0 of the previous panel q (both items U-type), whose k-loop the column
+        // wave parked in LDS (L.Wh) during the previous slot.  Finish them here (6 block products), store them for
+        // everybody else, and use them straight from registers as the last two k-steps of D00 / D01 / D11.
+        const int qpar = par ^ 1;
+        const f32x16 L0 = ldl(c.L.LT + (2 * qpar + 0) * BLK, lane);
+        const f32x16 L1 = ldl(c.L.LT + (2 * qpar + 1) * BLK, lane);
+        const f32x16 Uq = ldl(c.L.U01 + qpar * BLK, lane);
+        f32x16 X0[2], X1[2];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float zk = lds_f[c.L.z + 32 * k + rho(q, c.h)];
-                    tp0 = fmaf(A0[q], zk, tp0);
-                    tp1 = fmaf(A1[q], zk, tp1);
-                }
-                A0 = nA0; A1 = nA1;
-            }
+        for (int n = 0; n < 2; ++n) {
+            const f32x16 W0 = ldl(c.L.Wh + n * BLK, lane);
+            f32x16 W1 = ldl(c.L.Wh + (2 + n) * BLK, lane);
+            X0[n] = zero16();
+            mma_blk(X0[n], L0, W0);
+            f32x16 T = zero16();
+            mma_blk(T, Uq, X0[n]);
+            W1 -= T;
+            X1[n] = zero16();
+            mma_blk(X1[n], L1, W1);
+            stg(c.ws, q.j0 * NB + j0 + n, lane, X0[n]);        // item n of panel q is the U-type column j0 + n
+            stg(c.ws, q.j1 * NB + j0 + n, lane, X1[n]);
         }
+        mma_blk(D00, X0[0], X0[0]); mma_blk(D00, X1[0], X1[0]);
+        mma_blk(D01, X0[0], X0[1]); mma_blk(D01, X1[0], X1[1]);
+        mma_blk(D11, X0[1], X0[1]); mma_blk(D11, X1[1], X1[1]);
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) {
+            const float z0 = lds_f[c.L.z + 32 * q.j0 + rho(qq, c.h)], z1 = lds_f[c.L.z + 32 * q.j1 + rho(qq, c.h)];
+            tp0 = fmaf(X0[0][qq], z0, fmaf(X1[0][qq], z1, tp0));
+            tp1 = fmaf(X0[1][qq], z0, fmaf(X1[1][qq], z1, tp1));
+        }
+        // the column wave needs these rows for the k-loop it runs ahead at the end of this slot
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&sh->g0done, slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     PROF_END(c, 0);
     f32x16 S1keep = zero16();
@@ -711,10 +754,11 @@ __device__ __forceinline__ void phase_pt(Ctx<D, KN>& c, const bool want_m) {
     for (int s = 0; s <= NP; ++s) {
         const bool chain_busy = s < NP;                 // wave 0 runs the chain of panel s first
         if (chain_busy && w == 0) {
-            if (c.lane == 0) sh->gnext[(s + 1) & 1] = 2;     // queue head of the NEXT slot (groups 0,1: wave 1)
+            if (c.lane == 0) sh->gnext[(s + 1) & 1] = 2;     // queue head of the NEXT slot (groups 0,1: column wave)
             Panel<D> p = make_panel<D>(NB, s, want_m);
+            const Panel<D> q = make_panel<D>(NB, s > 0 ? s - 1 : 0, want_m);
             const int kwait = (s > 0) ? (p.j0 - 2) : p.j0;
-            pt_chain<D, KN>(c, p, want_m, s & 1, kwait, s);
+            pt_chain<D, KN>(c, p, q, want_m, s & 1, kwait, s, held);
         }
         PROF_BEGIN();
         if (s >= 1) {
@@ -723,7 +767,8 @@ __device__ __forceinline__ void phase_pt(Ctx<D, KN>& c, const bool want_m) {
             const int par = (s - 1) & 1;
             f32x16 W[4];
             if (w == 1) {
-                if (nGroups > 0) {
+                // group 0: while a chain is running the chain wave finishes it from the parked k-loop
+                if (nGroups > 0 && !(chain_busy && held)) {
                     if (held) {
 #pragma unroll
                         for (int n = 0; n < 4; ++n) W[n] = ldl(c.L.Wh + n * BLK, c.lane);
@@ -733,12 +778,11 @@ __device__ __forceinline__ void phase_pt(Ctx<D, KN>& c, const bool want_m) {
                     pt_group_row<D, KN>(c, q, 0, 0, par, W);
                     if (q.has1) pt_group_row<D, KN>(c, q, 0, 1, par, W);
                     if (chain_busy) {
-                        // rows j0(s-1), j1(s-1) of the chain's two columns are in memory: release the chain
+                        // not parked (odd NB tail): the chain of this slot waits for these rows
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (c.lane == 0) __hip_atomic_store(&sh->g0done, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
-                held = false;
                 PROF_END(c, 5);
                 if (nGroups > 1) {
                     pt_group_kloop<D, KN>(c, q, 1, W);
@@ -764,15 +808,22 @@ __device__ __forceinline__ void phase_pt(Ctx<D, KN>& c, const bool want_m) {
             // run ahead: k-loop of group 0 of panel s (the columns of the next chain); it only needs rows
             // < j0(s), all of which are in memory (the newest ones were written by this very wave)
             const Panel<D> pn = make_panel<D>(NB, s, want_m);
-            if (pn.nU >= 1) {
+            if (pn.nU >= 2) {
+                if (s >= 1 && held) {
+                    // rows of panel s-1 for the columns j0(s), j1(s) were written by the chain wave in this slot
+                    while (__hip_atomic_load(&sh->g0done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < s)
+                        __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
                 f32x16 W[4];
                 pt_group_kloop<D, KN>(c, pn, 0, W);
 #pragma unroll
                 for (int n = 0; n < 4; ++n) stl(c.L.Wh + n * BLK, c.lane, W[n]);
-                held = true;
                 PROF_END(c, 4);
             }
         }
+        // every wave tracks whether group 0 of panel s has been run ahead and parked
+        held = chain_busy && (make_panel<D>(NB, s, want_m).nU >= 2);
         __syncthreads();
         PROF_END(c, 3);
         if (sh->fail) break;
