@@ -12,7 +12,7 @@ radius for observations, strict ``<`` for prediction locations, source row order
 into one ragged batch and fitted + predicted by ONE ``gpsat_fit_predict_batch`` call per wave, and the reference's
 tables (``run_details``, ``preds``, ``lengthscales``, ``kernel_variance``, ``likelihood_variance``, ``expert_locs``,
 ``oi_config``; columns ``_dim_0``, ``f*``, ``f*_var``, ``y_var``, ``f_bar``, ``pred_loc_<c>`` ...) are produced with the
-expert coordinates as (Multi)Index.  The store is a directory of parquet files (pytables/HDF5 is not a dependency
+expert coordinates as (Multi)Index.  The store is a directory of pandas-pickled tables (pytables/HDF5 is not a dependency
 of this backend); re-running skips expert locations already present in ``run_details`` (resume,
 local_experts.py:475-497,908-912).
 
@@ -166,7 +166,8 @@ def _index_for(coords_col, loc_rows: np.ndarray):
 
 
 class ResultStore:
-    """Directory of parquet tables named ``<table><suffix>.parquet`` (+ ``oi_config<suffix>.json``)."""
+    """Directory of pandas-pickled tables named ``<table><suffix>.pkl`` (+ ``oi_config<suffix>.json``): no
+    dependency beyond pandas itself (pytables / pyarrow are not guaranteed on the GPU hosts)."""
 
     def __init__(self, path: Optional[str]):
         self.path = path
@@ -174,12 +175,12 @@ class ResultStore:
             os.makedirs(path, exist_ok=True)
 
     def _file(self, table):
-        return os.path.join(self.path, f"{table}.parquet")
+        return os.path.join(self.path, f"{table}.pkl")
 
     def read(self, table) -> Optional[pd.DataFrame]:
         if not self.path or not os.path.exists(self._file(table)):
             return None
-        return pd.read_parquet(self._file(table))
+        return pd.read_pickle(self._file(table))
 
     def append(self, table, df: pd.DataFrame):
         if not self.path or df is None or len(df) == 0:
@@ -187,14 +188,14 @@ class ResultStore:
         old = self.read(table)
         if old is not None:
             df = pd.concat([old, df])
-        df.to_parquet(self._file(table))
+        df.to_pickle(self._file(table))
 
     def tables(self) -> Dict[str, pd.DataFrame]:
         out = {}
         if self.path:
             for f in sorted(os.listdir(self.path)):
-                if f.endswith(".parquet"):
-                    out[f[:-8]] = pd.read_parquet(os.path.join(self.path, f))
+                if f.endswith(".pkl"):
+                    out[f[:-4]] = pd.read_pickle(os.path.join(self.path, f))
         return out
 
 
