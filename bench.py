@@ -121,18 +121,36 @@ def main():
     ap.add_argument("--wg-per-cu", type=int, default=0)
     a = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
     from gpsat_amd import _lib as L
-    from gpsat_amd.engine import Engine
     from gpsat_amd import synthetic as syn
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if a.gpus != world and world == 1 and a.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+
+    T, N, P, D = a.tiles, a.nobs, a.npred, a.dim
+    kid = L.KERNEL_IDS[a.kernel]
+    H = D + 2
+    ncpu = os.cpu_count() or 1
+    workers = max(1, min(16, ncpu // max(1, min(world, 8))))
+    # ---- host-side work that forks worker processes happens BEFORE the GPU / RCCL are initialised
+    X, y, Xs, obs_off, pred_off = make_tiles(T, N, P, D, kid, base_seed=1_000_000 * rank, workers=workers)
+    cpu = None
+    n_cpu_tiles = a.cpu_tiles if a.cpu_tiles >= 0 else (2 * workers if world == 1 else 0)
+    if rank == 0 and n_cpu_tiles > 0:
+        v, e_cpu, wall = cpu_baseline(X, y, Xs, N, P, D, kid, a.max_iter, n_cpu_tiles, workers)
+        cpu = {"value": round(v, 3), "unit": "tiles/s", "cores": workers, "kind": "port",
+               "sample": f"{n_cpu_tiles} of the same tiles, fp64 NumPy/SciPy oracle "
+                         f"(L-BFGS-B maxiter={a.max_iter}, {e_cpu:.1f} evals/tile, predict P={P}), "
+                         f"one single-threaded process per core, {wall:.1f}s wall"}
+
+    import torch
+    import torch.distributed as dist
+    from gpsat_amd.engine import Engine
+    from gpsat_amd.sharding import all_gather_equal
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -141,12 +159,6 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    T, N, P, D = a.tiles, a.nobs, a.npred, a.dim
-    kid = L.KERNEL_IDS[a.kernel]
-    H = D + 2
-    ncpu = os.cpu_count() or 1
-    workers = max(1, min(16, ncpu // max(1, min(world, 8))))
-    X, y, Xs, obs_off, pred_off = make_tiles(T, N, P, D, kid, base_seed=1_000_000 * rank, workers=workers)
     dX, dy, dXs = (torch.from_numpy(v).to(dev) for v in (X, y, Xs))
     fm = torch.empty(T * P, dtype=torch.float32, device=dev)
     fv = torch.empty_like(fm)
@@ -163,11 +175,7 @@ def main():
             # final gather of per-tile hyper-parameters + predictions (the only collective of the path)
             fixed = torch.from_numpy(np.concatenate([r.theta, r.nll[:, None], r.status[:, None].astype(np.float64),
                                                      r.n_eval[:, None].astype(np.float64)], axis=1)).to(dev)
-            fl = [torch.empty_like(fixed) for _ in range(world)]
-            dist.all_gather(fl, fixed)
-            preds = torch.stack([fm, fv, yv], dim=1)
-            pl = [torch.empty_like(preds) for _ in range(world)]
-            dist.all_gather(pl, preds)
+            all_gather_equal(fixed, torch.stack([fm, fv, yv], dim=1), world)
         return r
 
     def barrier():
@@ -215,13 +223,8 @@ def main():
                          "kernel": f"gp_tile_kernel<{D}, {kid}>", "kernel_ms": round(k_ms, 3),
                          "flops_per_launch": flops_launch},
         }
-        n_cpu_tiles = a.cpu_tiles if a.cpu_tiles >= 0 else (2 * workers if world == 1 else 0)
-        if n_cpu_tiles > 0:
-            v, e_cpu, wall = cpu_baseline(X, y, Xs, N, P, D, kid, a.max_iter, n_cpu_tiles, workers)
-            out["cpu_baseline"] = {"value": round(v, 3), "unit": "tiles/s", "cores": workers, "kind": "port",
-                                   "sample": f"{n_cpu_tiles} of the same tiles, fp64 NumPy/SciPy oracle "
-                                             f"(L-BFGS-B maxiter={a.max_iter}, {e_cpu:.1f} evals/tile, predict P={P}), "
-                                             f"one single-threaded process per core, {wall:.1f}s wall"}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -101,3 +101,15 @@ def gather_results(fixed, preds, pred_counts, tile_index, world_size, rank, devi
     pred_off_g = np.concatenate([[0], np.cumsum(counts_g)])
     preds_g = np.concatenate([chunks[t] for t in range(Ttot)], axis=0) if Ttot else np.zeros((0, 3), np.float32)
     return fixed_g, preds_g, pred_off_g
+
+
+def all_gather_equal(fixed, preds, world_size):
+    """Equal-size variant used by the weak-scaling bench (every rank owns the same number of tiles and
+    predictions): two all_gather calls, rank-major order = global tile order.  Returns (fixed_all, preds_all)."""
+    import torch
+    import torch.distributed as dist
+    fl = [torch.empty_like(fixed) for _ in range(world_size)]
+    dist.all_gather(fl, fixed)
+    pl = [torch.empty_like(preds) for _ in range(world_size)]
+    dist.all_gather(pl, preds)
+    return torch.cat(fl, dim=0), torch.cat(pl, dim=0)

@@ -37,6 +37,10 @@ def _worker(rank, world, port, ret):
         preds = torch.tensor(np.concatenate([np.full((c, 3), float(t)) + np.arange(c)[:, None] * 0.01
                                              for t, c in zip(mine, cnt)] + [np.zeros((0, 3))]), dtype=torch.float32)
         out = sharding.gather_results(fixed, preds, cnt, mine, world, rank)
+        # equal-size variant used by bench.py
+        fa, pa = sharding.all_gather_equal(torch.full((3, 2), float(rank)), torch.full((5, 3), float(rank) + 0.5), world)
+        assert fa.shape == (3 * world, 2) and pa.shape == (5 * world, 3)
+        assert fa[:3].eq(0).all() and fa[3:].eq(1).all() and pa[5:].eq(1.5).all()
         if rank == 0:
             fg, pg, off = out
             ok = True
