@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--max-iter", type=int, default=20)
     ap.add_argument("--cpu-tiles", type=int, default=-1, help="tiles in the CPU baseline sample (0 = skip)")
     ap.add_argument("--wg-per-cu", type=int, default=0)
+    ap.add_argument("--workers", type=int, default=0, help="host processes for data generation / CPU baseline "
+                    "(0 = auto; use 1 under rocprofv3 --pmc: no fork beside the profiler)")
     a = ap.parse_args()
 
     from gpsat_amd import _lib as L
@@ -134,7 +136,7 @@ def main():
     kid = L.KERNEL_IDS[a.kernel]
     H = D + 2
     ncpu = os.cpu_count() or 1
-    workers = max(1, min(16, ncpu // max(1, min(world, 8))))
+    workers = a.workers if a.workers > 0 else max(1, min(16, ncpu // max(1, min(world, 8))))
     # ---- host-side work that forks worker processes happens BEFORE the GPU / RCCL are initialised
     X, y, Xs, obs_off, pred_off = make_tiles(T, N, P, D, kid, base_seed=1_000_000 * rank, workers=workers)
     cpu = None
