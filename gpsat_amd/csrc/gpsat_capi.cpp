@@ -130,7 +130,9 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     if (b->T < 0) return fail(GPSAT_EINVAL, "T < 0");
     if (b->T == 0) return GPSAT_OK;
     if (b->D < 1 || b->D > 3) return fail(GPSAT_EINVAL, "D must be 1..3 in this build");
-    if (b->dtype != GPSAT_F32) return fail(GPSAT_EINVAL, "dtype: only GPSAT_F32 is built");
+    if (b->dtype != GPSAT_F32 && b->dtype != GPSAT_F64) return fail(GPSAT_EINVAL, "unknown dtype");
+    const bool f64 = b->dtype == GPSAT_F64;
+    const size_t esz = f64 ? sizeof(double) : sizeof(float);
     if (b->kernel < 0 || b->kernel > 3) return fail(GPSAT_EINVAL, "unknown kernel id");
     if (b->optimiser < 0 || b->optimiser > 2) return fail(GPSAT_EINVAL, "unknown optimiser id");
     if (b->memory != GPSAT_MEM_HOST && b->memory != GPSAT_MEM_DEVICE) return fail(GPSAT_EINVAL, "bad memory flag");
@@ -147,7 +149,8 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
         maxN = std::max(maxN, n);
     }
     const long long sumN = b->obs_off[T], sumP = b->pred_off[T];
-    if (maxN > 4096) return fail(GPSAT_EINVAL, "tile with more than 4096 observations is not supported by this build");
+    if (maxN > (f64 ? 2048 : 4096))
+        return fail(GPSAT_EINVAL, "tile too large for this build (4096 observations in fp32, 2048 in fp64)");
     if (sumN > 0 && (!b->X || !b->y)) return fail(GPSAT_EINVAL, "X / y is NULL");
     if (sumP > 0 && (!b->Xs || !b->f_mean || !b->f_var || !b->y_var)) return fail(GPSAT_EINVAL, "prediction pointer is NULL");
     for (int t = 0; t < T; ++t)
@@ -155,7 +158,8 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
             const double v = b->theta0[(size_t)t * H + i];
             if (!(v > 0.0) || !std::isfinite(v)) return fail(GPSAT_EINVAL, "theta0 must be finite and positive");
         }
-    const int NBmax = std::max(1, (int)((maxN + 31) / 32));
+    const int bs = f64 ? 16 : 32;
+    const int NBmax = std::max(1, (int)((maxN + bs - 1) / bs));
 
     HIP_TRY(hipSetDevice(h->device));
     // ---- tile order: largest cost first (N^3), stable so equal tiles keep the reference order
@@ -174,32 +178,32 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     if ((rc = h->meta_misc.reserve((size_t)T * sizeof(int) + 64 + 16))) return rc;
     if ((rc = h->out_f64.reserve(((size_t)T * H * 2 + (size_t)T) * sizeof(double)))) return rc;
     if ((rc = h->out_i32.reserve((size_t)T * 2 * sizeof(int)))) return rc;
-    const size_t wsf = gpsat::workspace_floats_per_wg(NBmax);
+    const size_t wsf = f64 ? gpsat::workspace_doubles_per_wg_f64(NBmax) : gpsat::workspace_floats_per_wg(NBmax);
     int grid = std::min(T, h->num_cu * h->wg_per_cu);
-    const size_t smem = gpsat::shared_bytes(D, NBmax);
+    const size_t smem = f64 ? gpsat::shared_bytes_f64(D, NBmax) : gpsat::shared_bytes(D, NBmax);
     if (smem > 160 * 1024) return fail(GPSAT_EINVAL, "tile too large for LDS");
-    if (smem > 80 * 1024) grid = std::min(grid, h->num_cu);
-    if ((rc = h->ws.reserve((size_t)grid * wsf * sizeof(float)))) return rc;
+    if (smem > 80 * 1024 || f64) grid = std::min(grid, h->num_cu);
+    if ((rc = h->ws.reserve((size_t)grid * wsf * esz))) return rc;
 
-    const float *dX = nullptr, *dy = nullptr, *dXs = nullptr;
-    float *dfm = nullptr, *dfv = nullptr, *dyv = nullptr;
+    const char *dX = nullptr, *dy = nullptr, *dXs = nullptr;
+    char *dfm = nullptr, *dfv = nullptr, *dyv = nullptr;
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     if (b->memory == GPSAT_MEM_HOST) {
-        const size_t in_f = (size_t)sumN * D + (size_t)sumN + (size_t)sumP * D;
-        if ((rc = h->bulk_in.reserve(std::max<size_t>(in_f, 1) * sizeof(float)))) return rc;
-        if ((rc = h->bulk_out.reserve(std::max<size_t>((size_t)sumP * 3, 1) * sizeof(float)))) return rc;
-        float* base = static_cast<float*>(h->bulk_in.p);
+        const size_t in_e = (size_t)sumN * D + (size_t)sumN + (size_t)sumP * D;
+        if ((rc = h->bulk_in.reserve(std::max<size_t>(in_e, 1) * esz))) return rc;
+        if ((rc = h->bulk_out.reserve(std::max<size_t>((size_t)sumP * 3, 1) * esz))) return rc;
+        char* base = static_cast<char*>(h->bulk_in.p);
+        dX = base; dy = base + (size_t)sumN * D * esz; dXs = base + (size_t)sumN * (D + 1) * esz;
         if (sumN > 0) {
-            HIP_TRY(hipMemcpyAsync(base, b->X, (size_t)sumN * D * sizeof(float), hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(hipMemcpyAsync(base + (size_t)sumN * D, b->y, (size_t)sumN * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(const_cast<char*>(dX), b->X, (size_t)sumN * D * esz, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(const_cast<char*>(dy), b->y, (size_t)sumN * esz, hipMemcpyHostToDevice, h->stream));
         }
         if (sumP > 0)
-            HIP_TRY(hipMemcpyAsync(base + (size_t)sumN * (D + 1), b->Xs, (size_t)sumP * D * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        dX = base; dy = base + (size_t)sumN * D; dXs = base + (size_t)sumN * (D + 1);
-        dfm = static_cast<float*>(h->bulk_out.p); dfv = dfm + sumP; dyv = dfv + sumP;
+            HIP_TRY(hipMemcpyAsync(const_cast<char*>(dXs), b->Xs, (size_t)sumP * D * esz, hipMemcpyHostToDevice, h->stream));
+        dfm = static_cast<char*>(h->bulk_out.p); dfv = dfm + (size_t)sumP * esz; dyv = dfv + (size_t)sumP * esz;
     } else {
-        dX = static_cast<const float*>(b->X); dy = static_cast<const float*>(b->y); dXs = static_cast<const float*>(b->Xs);
-        dfm = static_cast<float*>(b->f_mean); dfv = static_cast<float*>(b->f_var); dyv = static_cast<float*>(b->y_var);
+        dX = static_cast<const char*>(b->X); dy = static_cast<const char*>(b->y); dXs = static_cast<const char*>(b->Xs);
+        dfm = static_cast<char*>(b->f_mean); dfv = static_cast<char*>(b->f_var); dyv = static_cast<char*>(b->y_var);
     }
     long long* d_i64 = static_cast<long long*>(h->meta_i64.p);
     HIP_TRY(hipMemcpyAsync(d_i64, b->obs_off, (size_t)(T + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
@@ -218,23 +222,23 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
 
     gpsat::KernelArgs a;
     a.T = T; a.kernel = b->kernel; a.optimiser = b->optimiser; a.max_iter = b->max_iter;
-    a.max_ls = b->max_ls > 0 ? b->max_ls : 10;
+    a.max_ls = b->max_ls > 0 ? b->max_ls : (f64 ? 20 : 10);
     a.NBmax = NBmax;
-    a.ftol = b->ftol > 0 ? b->ftol : 1e-6;
+    a.ftol = b->ftol > 0 ? b->ftol : (f64 ? 2.220446049250313e-9 : 1e-6);   // SciPy factr*eps in fp64
     a.gtol = b->gtol > 0 ? b->gtol : 1e-5;
     a.adam_lr = b->adam_lr > 0 ? b->adam_lr : 0.1;
     a.obs_off = d_i64; a.pred_off = d_i64 + (T + 1);
     a.theta0 = d_f64; a.lo = d_f64 + (size_t)T * H; a.hi = d_f64 + 2 * (size_t)T * H;
     a.trainable = d_train;
-    a.X = dX; a.y = dy; a.Xs = dXs;
+    a.X = reinterpret_cast<const float*>(dX); a.y = reinterpret_cast<const float*>(dy); a.Xs = reinterpret_cast<const float*>(dXs);
     double* d_out = static_cast<double*>(h->out_f64.p);
     a.theta = d_out; a.nll = d_out + (size_t)T * H;
     a.grad = b->grad ? d_out + (size_t)T * H + T : nullptr;
     int* d_oi = static_cast<int*>(h->out_i32.p);
     a.status = d_oi; a.n_eval = d_oi + T;
-    a.f_mean = dfm; a.f_var = dfv; a.y_var = dyv;
+    a.f_mean = reinterpret_cast<float*>(dfm); a.f_var = reinterpret_cast<float*>(dfv); a.y_var = reinterpret_cast<float*>(dyv);
     a.order = d_order; a.queue = d_queue;
-    a.ws = static_cast<float*>(h->ws.p); a.ws_stride = wsf;
+    a.ws = static_cast<float*>(h->ws.p); a.ws_stride = wsf;     // fp64: the kernel reinterprets ws as doubles
     a.prof = nullptr;
 #ifdef GPSAT_PROFILE
     if ((rc = h->prof.reserve(64 * sizeof(unsigned long long)))) return rc;
@@ -243,7 +247,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
 #endif
 
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-    HIP_TRY(gpsat::launch_tiles(D, a, grid, smem, h->stream));
+    HIP_TRY(f64 ? gpsat::launch_tiles_f64(D, a, grid, smem, h->stream) : gpsat::launch_tiles(D, a, grid, smem, h->stream));
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
 
     HIP_TRY(hipMemcpyAsync(b->theta, a.theta, (size_t)T * H * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -252,9 +256,9 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     HIP_TRY(hipMemcpyAsync(b->status, a.status, (size_t)T * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(b->n_eval, a.n_eval, (size_t)T * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (b->memory == GPSAT_MEM_HOST && sumP > 0) {
-        HIP_TRY(hipMemcpyAsync(b->f_mean, dfm, (size_t)sumP * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipMemcpyAsync(b->f_var, dfv, (size_t)sumP * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipMemcpyAsync(b->y_var, dyv, (size_t)sumP * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(b->f_mean, dfm, (size_t)sumP * esz, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(b->f_var, dfv, (size_t)sumP * esz, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(b->y_var, dyv, (size_t)sumP * esz, hipMemcpyDeviceToHost, h->stream));
     }
 #ifdef GPSAT_PROFILE
     HIP_TRY(hipMemcpyAsync(h->prof_host, h->prof.p, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));

@@ -35,6 +35,10 @@ struct KernelArgs {
 };
 
 size_t shared_bytes(int D, int NBmax);
+// fp64 kernels (gpsat_kernels_f64.hip): X, y, Xs, f_* and ws of KernelArgs point at doubles, ws_stride counts doubles
+size_t shared_bytes_f64(int D, int NBmax);
+size_t workspace_doubles_per_wg_f64(int NBmax);
+hipError_t launch_tiles_f64(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream);
 size_t workspace_floats_per_wg(int NBmax);
 hipError_t launch_tiles(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream);
 

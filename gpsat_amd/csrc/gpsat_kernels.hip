@@ -55,11 +55,7 @@ extern __shared__ __attribute__((aligned(16))) float lds_f[];
 
 __device__ __forceinline__ int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-constexpr int NW = 4;          // waves per workgroup
-constexpr int NT = 256;        // threads per workgroup
 constexpr int BLK = 1024;      // floats per block
-constexpr int HMAX = 6;        // max D + 2 (D <= 4)
-constexpr int MH = 8;          // L-BFGS history
 
 // ---------------------------------------------------------------------------------------------
 // block movement (acc layout) and the MFMA chain
@@ -161,36 +157,7 @@ __device__ __forceinline__ void kfun(float r2, float& kf, float& gg) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// per-workgroup state
-// ---------------------------------------------------------------------------------------------
-struct Shared {
-    // evaluation interface
-    double theta[HMAX];
-    double gth[HMAX];          // dNLL/dtheta
-    double nll;
-    double logdet;
-    double red[NW][8];
-    // optimiser state (thread 0 writes, everybody reads after a barrier)
-    double lo[HMAX], hi[HMAX], shift[HMAX];
-    double u[HMAX], g[HMAX], f;            // current accepted point (u-space)
-    double ut[HMAX], gt[HMAX], ft;         // trial point
-    double d[HMAX];
-    double S[MH][HMAX], Y[MH][HMAX], rho_[MH];
-    double m1[HMAX], m2[HMAX];             // Adam moments
-    // line search
-    double t, t_prev, f_prev, dphi_prev, t_lo, f_lo, dphi_lo, t_hi, f_hi, dphi_hi, dphi0, t_best, f_best, last_dec;
-    int ls_phase, ls_iter, ls_done, ls_ok;
-    int hist_n, hist_pos;
-    int trainable[HMAX];
-    int box[HMAX];
-    int fail, done, status, n_eval, n_eval_opt, iter, phase, want_grad;
-    int tile;
-    int g0done;                 // slot index up to which group 0 of the previous panel is in memory
-    int gnext[2];               // dynamic group queue heads of the PT slots (alternating) 
-    int gradnext;               // dynamic group queue head of the gradient phase
-    unsigned long long prof[NW * 16];
-};
+#include "gpsat_opt.h"
 
 constexpr int SHARED_FLOATS = (int)((sizeof(Shared) + 15) / 16) * 4;
 
@@ -1054,271 +1021,6 @@ __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const float* __restr
             const float var = c.sf2 - vsb;
             fm[qb] = msb; fv[qb] = var; yv[qb] = var + c.sn2;
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// parameter transforms (reference GPSat/utils.py:2320-2400,
-// GPSat/models/gpflow_models.py:490-494): box -> lo + (hi-lo) sigmoid(u); else softplus(u) + shift
-// ---------------------------------------------------------------------------------------------
-__device__ inline double softplus_d(double x) { return log1p(exp(-fabs(x))) + fmax(x, 0.0); }
-
-__device__ __noinline__ double theta_of_u(const Shared* sh, int i, double u) {
-    if (sh->box[i]) return sh->lo[i] + (sh->hi[i] - sh->lo[i]) / (1.0 + exp(-u));
-    return softplus_d(u) + sh->shift[i];
-}
-
-__device__ __noinline__ double u_of_theta(const Shared* sh, int i, double th) {
-    if (sh->box[i]) {
-        const double lo = sh->lo[i], hi = sh->hi[i];
-        double t = (th - lo) / (hi - lo);
-        t = fmin(fmax(t, 1e-15), 1.0 - 1e-15);
-        return log(t / (1.0 - t));
-    }
-    double y = th - sh->shift[i];
-    if (y < 1e-300) y = 1e-300;
-    if (y > 34.0) return y;
-    if (y < 1e-15) return log(y);
-    return log(-expm1(-y)) + y;
-}
-
-__device__ inline double dtheta_du(const Shared* sh, int i, double th) {
-    if (sh->box[i]) return (th - sh->lo[i]) * (sh->hi[i] - th) / (sh->hi[i] - sh->lo[i]);
-    return -expm1(-(th - sh->shift[i]));
-}
-
-// thread 0: trial u -> theta for the next evaluation
-__device__ __noinline__ void set_trial(Shared* sh, int H, const double* u) {
-    for (int i = 0; i < H; ++i) {
-        sh->ut[i] = u[i];
-        if (sh->trainable[i]) sh->theta[i] = theta_of_u(sh, i, u[i]);
-    }
-}
-
-// thread 0: after an evaluation, chain the gradient to u-space at the trial point
-__device__ __noinline__ void fetch_trial(Shared* sh, int H) {
-    sh->ft = sh->fail ? __builtin_inf() : sh->nll;
-    for (int i = 0; i < H; ++i)
-        sh->gt[i] = (sh->trainable[i] && !sh->fail) ? sh->gth[i] * dtheta_du(sh, i, sh->theta[i]) : 0.0;
-}
-
-// L-BFGS two-loop recursion (thread 0): d = -H g
-__device__ __noinline__ void lbfgs_direction(Shared* sh, int H) {
-    double q[HMAX], al[MH];
-    for (int i = 0; i < H; ++i) q[i] = sh->g[i];
-    const int n = sh->hist_n;
-    for (int m = 0; m < n; ++m) {
-        const int idx = (sh->hist_pos - 1 - m + 2 * MH) % MH;
-        double a = 0.0;
-        for (int i = 0; i < H; ++i) a += sh->S[idx][i] * q[i];
-        a *= sh->rho_[idx];
-        al[m] = a;
-        for (int i = 0; i < H; ++i) q[i] -= a * sh->Y[idx][i];
-    }
-    if (n > 0) {
-        const int idx = (sh->hist_pos - 1 + MH) % MH;
-        double sy = 0.0, yy = 0.0;
-        for (int i = 0; i < H; ++i) { sy += sh->S[idx][i] * sh->Y[idx][i]; yy += sh->Y[idx][i] * sh->Y[idx][i]; }
-        const double gam = sy / yy;
-        for (int i = 0; i < H; ++i) q[i] *= gam;
-    }
-    for (int m = n - 1; m >= 0; --m) {
-        const int idx = (sh->hist_pos - 1 - m + 2 * MH) % MH;
-        double b = 0.0;
-        for (int i = 0; i < H; ++i) b += sh->Y[idx][i] * q[i];
-        b *= sh->rho_[idx];
-        for (int i = 0; i < H; ++i) q[i] += (al[m] - b) * sh->S[idx][i];
-    }
-    for (int i = 0; i < H; ++i) sh->d[i] = -q[i];
-}
-
-__device__ inline double cubic_min(double a, double fa, double da, double b, double fb, double db) {
-    // minimiser of the cubic interpolating (a,fa,da), (b,fb,db); falls back to bisection
-    const double d1 = da + db - 3.0 * (fa - fb) / (a - b);
-    const double rad = d1 * d1 - da * db;
-    if (!(rad >= 0.0)) return 0.5 * (a + b);
-    double d2 = sqrt(rad);
-    if (b < a) d2 = -d2;
-    const double den = db - da + 2.0 * d2;
-    if (den == 0.0) return 0.5 * (a + b);
-    const double t = b - (b - a) * ((db + d2 - d1) / den);
-    if (!(t == t)) return 0.5 * (a + b);
-    return t;
-}
-
-// strong-Wolfe line search step (thread 0).  Called after each trial evaluation.
-// Sets sh->ls_done (1 accepted / 2 failed) or the next sh->t.
-__device__ __noinline__ void ls_step(Shared* sh, int H, int max_ls) {
-    const double c1 = 1e-4, c2 = 0.9;
-    const double t = sh->t, ft = sh->ft;
-    double dphit = 0.0;
-    for (int i = 0; i < H; ++i) dphit += sh->gt[i] * sh->d[i];
-    const bool finite = (ft == ft) && (ft < 1e300);
-    const bool armijo = finite && (ft <= sh->f + c1 * t * sh->dphi0);
-    if (armijo && ft < sh->f_best) { sh->f_best = ft; sh->t_best = t; }
-    sh->ls_iter += 1;
-    if (armijo && fabs(dphit) <= -c2 * sh->dphi0) { sh->ls_done = 1; return; }
-    if (sh->ls_iter >= max_ls) { sh->ls_done = (armijo ? 1 : 2); return; }
-    if (sh->ls_phase == 0) {
-        if (!armijo || (sh->ls_iter > 1 && ft >= sh->f_prev)) {
-            sh->t_lo = sh->t_prev; sh->f_lo = sh->f_prev; sh->dphi_lo = sh->dphi_prev;
-            sh->t_hi = t; sh->f_hi = ft; sh->dphi_hi = dphit;
-            sh->ls_phase = 1;
-        } else if (dphit >= 0.0) {
-            sh->t_lo = t; sh->f_lo = ft; sh->dphi_lo = dphit;
-            sh->t_hi = sh->t_prev; sh->f_hi = sh->f_prev; sh->dphi_hi = sh->dphi_prev;
-            sh->ls_phase = 1;
-        } else {
-            sh->t_prev = t; sh->f_prev = ft; sh->dphi_prev = dphit;
-            sh->t = 2.0 * t;
-            return;
-        }
-    } else {
-        if (!armijo || ft >= sh->f_lo) {
-            sh->t_hi = t; sh->f_hi = ft; sh->dphi_hi = dphit;
-        } else {
-            if (dphit * (sh->t_hi - sh->t_lo) >= 0.0) { sh->t_hi = sh->t_lo; sh->f_hi = sh->f_lo; sh->dphi_hi = sh->dphi_lo; }
-            sh->t_lo = t; sh->f_lo = ft; sh->dphi_lo = dphit;
-        }
-    }
-    // next trial inside (lo, hi)
-    const double lo = sh->t_lo, hi = sh->t_hi;
-    double tn;
-    const bool hi_finite = (sh->f_hi == sh->f_hi) && (sh->f_hi < 1e300);
-    if (hi_finite) tn = cubic_min(lo, sh->f_lo, sh->dphi_lo, hi, sh->f_hi, sh->dphi_hi);
-    else tn = 0.5 * (lo + hi);
-    const double a = fmin(lo, hi), b = fmax(lo, hi), wdt = b - a;
-    if (!(tn > a + 0.1 * wdt && tn < b - 0.1 * wdt)) tn = 0.5 * (a + b);
-    if (wdt < 1e-12 * fmax(1.0, b)) { sh->ls_done = (armijo ? 1 : 2); return; }
-    sh->t = tn;
-}
-
-// ---------------------------------------------------------------------------------------------
-// optimiser driver (thread 0): a state machine advanced once per objective evaluation, so that the
-// kernel has ONE inlined call site of evaluate().
-// ---------------------------------------------------------------------------------------------
-enum { PH_INIT = 0, PH_LS = 1, PH_ADAM = 2, PH_FINAL = 3, PH_EXIT = 4 };
-
-struct OptCfg { int optimiser, max_iter, max_ls, want_grad_out; double ftol, gtol, adam_lr; };
-
-// the accepted point is sh->u; decide whether the factorisation in memory already belongs to it
-__device__ __noinline__ void opt_finish(Shared* sh, int H, const OptCfg& o, bool factor_is_current) {
-    sh->n_eval_opt = sh->n_eval;
-    if (factor_is_current && !sh->fail) { sh->phase = PH_EXIT; return; }
-    set_trial(sh, H, sh->u);
-    sh->want_grad = o.want_grad_out;
-    sh->phase = PH_FINAL;
-}
-
-__device__ __noinline__ void opt_start_iteration(Shared* sh, int H, const OptCfg& o) {
-    if (o.optimiser == 2) {
-        const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
-        const int k = sh->iter + 1;
-        double un[HMAX];
-        for (int i = 0; i < H; ++i) {
-            sh->m1[i] = b1 * sh->m1[i] + (1 - b1) * sh->g[i];
-            sh->m2[i] = b2 * sh->m2[i] + (1 - b2) * sh->g[i] * sh->g[i];
-            const double mh = sh->m1[i] / (1 - pow(b1, (double)k)), vh = sh->m2[i] / (1 - pow(b2, (double)k));
-            un[i] = sh->u[i] - (sh->trainable[i] ? o.adam_lr * mh / (sqrt(vh) + eps) : 0.0);
-        }
-        set_trial(sh, H, un);
-        sh->phase = PH_ADAM;
-        return;
-    }
-    lbfgs_direction(sh, H);
-    double dphi0 = 0.0, gn = 0.0;
-    for (int i = 0; i < H; ++i) { dphi0 += sh->g[i] * sh->d[i]; gn += sh->g[i] * sh->g[i]; }
-    if (!(dphi0 < 0.0)) {      // not a descent direction: restart from steepest descent
-        sh->hist_n = 0;
-        for (int i = 0; i < H; ++i) sh->d[i] = -sh->g[i];
-        dphi0 = -gn;
-    }
-    if (gn == 0.0) { sh->status = 0; opt_finish(sh, H, o, true); return; }
-    sh->dphi0 = dphi0;
-    sh->t = (sh->hist_n == 0) ? fmin(1.0, 1.0 / sqrt(gn)) : 1.0;
-    sh->ls_phase = 0; sh->ls_iter = 0; sh->ls_done = 0;
-    sh->t_prev = 0.0; sh->f_prev = sh->f; sh->dphi_prev = dphi0;
-    sh->t_best = 0.0; sh->f_best = sh->f;
-    double un[HMAX];
-    for (int i = 0; i < H; ++i) un[i] = sh->u[i] + sh->t * sh->d[i];
-    set_trial(sh, H, un);
-    sh->phase = PH_LS;
-}
-
-__device__ __noinline__ void opt_advance(Shared* sh, int H, const OptCfg& o) {
-    switch (sh->phase) {
-        case PH_INIT: {
-            set_trial(sh, H, sh->u);
-            fetch_trial(sh, H);
-            sh->f = sh->ft;
-            for (int i = 0; i < H; ++i) sh->g[i] = sh->gt[i];
-            if (sh->fail) { sh->status = 2; sh->n_eval_opt = sh->n_eval; sh->phase = PH_EXIT; return; }
-            sh->status = 1;
-            opt_start_iteration(sh, H, o);
-            return;
-        }
-        case PH_ADAM: {
-            fetch_trial(sh, H);
-            if (sh->fail) { sh->status = 2; opt_finish(sh, H, o, false); return; }
-            sh->f = sh->ft;
-            for (int i = 0; i < H; ++i) { sh->u[i] = sh->ut[i]; sh->g[i] = sh->gt[i]; }
-            sh->iter += 1;
-            if (sh->iter >= o.max_iter) { sh->status = 1; opt_finish(sh, H, o, true); return; }
-            opt_start_iteration(sh, H, o);
-            return;
-        }
-        case PH_LS: {
-            fetch_trial(sh, H);
-            ls_step(sh, H, o.max_ls);
-            if (!sh->ls_done) {
-                double un[HMAX];
-                for (int i = 0; i < H; ++i) un[i] = sh->u[i] + sh->t * sh->d[i];
-                set_trial(sh, H, un);
-                return;
-            }
-            if (sh->ls_done == 1) {
-                // accept the trial point (the last evaluated one)
-                double sy = 0.0, yy = 0.0, gmax = 0.0;
-                double sv[HMAX], yvv[HMAX];
-                for (int i = 0; i < H; ++i) {
-                    sv[i] = sh->ut[i] - sh->u[i];
-                    yvv[i] = sh->gt[i] - sh->g[i];
-                    sy += sv[i] * yvv[i];
-                    yy += yvv[i] * yvv[i];
-                }
-                if (sy > 1e-10 * yy && yy > 0.0) {
-                    const int pos = sh->hist_pos;
-                    for (int i = 0; i < H; ++i) { sh->S[pos][i] = sv[i]; sh->Y[pos][i] = yvv[i]; }
-                    sh->rho_[pos] = 1.0 / sy;
-                    sh->hist_pos = (pos + 1) % MH;
-                    if (sh->hist_n < MH) sh->hist_n += 1;
-                }
-                const double fold = sh->f, fnew = sh->ft;
-                sh->f = fnew;
-                sh->last_dec = fold - fnew;
-                for (int i = 0; i < H; ++i) { sh->u[i] = sh->ut[i]; sh->g[i] = sh->gt[i]; gmax = fmax(gmax, fabs(sh->gt[i])); }
-                sh->iter += 1;
-                const double den = fmax(fmax(fabs(fold), fabs(fnew)), 1.0);
-                if ((fold - fnew) <= o.ftol * den || gmax <= o.gtol) { sh->status = 0; opt_finish(sh, H, o, true); return; }
-                if (sh->iter >= o.max_iter) { sh->status = 1; opt_finish(sh, H, o, true); return; }
-                opt_start_iteration(sh, H, o);
-                return;
-            }
-            // line search failed: no further decrease is resolvable at this precision.  Restart from steepest
-            // descent only when the last accepted step still made real progress (far from the noise floor).
-            if (sh->hist_n > 0 && sh->iter + 1 < o.max_iter && sh->last_dec > 1e3 * o.ftol * fmax(fabs(sh->f), 1.0)) {
-                sh->hist_n = 0;           // one restart with steepest descent from the accepted point
-                sh->iter += 1;
-                opt_start_iteration(sh, H, o);
-                return;
-            }
-            sh->status = (sh->iter + 1 >= o.max_iter && sh->hist_n > 0) ? 1 : 0;
-            opt_finish(sh, H, o, false);
-            return;
-        }
-        default:  // PH_FINAL
-            sh->phase = PH_EXIT;
-            return;
     }
 }
 

@@ -1,0 +1,606 @@
+// gpsat_kernels_f64.hip -- fp64 variant of the persistent local-expert tile kernel (gfx950).
+//
+// Same algorithm, same data-layout idea and the same on-device optimiser as the fp32 kernel
+// (gpsat_kernels.hip), on 16x16 fp64 blocks and v_mfma_f64_16x16x4_f64:
+//   * "acc layout" of a block = the f64 MFMA accumulator: lane l = 16*q + g owns column g and the rows
+//     q + 4r, r = 0..3 (NOT the f32 row map); 4 doubles per lane, 32 contiguous bytes per lane in memory;
+//   * a stored block S acts as S^T as the A operand and as S as the B operand (MFMA step s contracts the rows
+//     q + 4s), an accumulator is directly a B operand, so every product is S_A^T * S_B;
+//   * K = U^T U (upper), M = L^-1 (lower), (K^-1)_ab = sum_c M_ca^T M_cb contracted on the fly with dK/dtheta.
+// This first fp64 version keeps the simple schedule (one block row per step, one workgroup barrier pair per
+// row, one block column of M per wave); it exists for the reference's native precision (GPflow default_float,
+// fp64 throughout) -- 1e-6-level known-answer parity and BASELINE config 5 (N = 2000,
+// predict-only with loaded hyper-parameters).  Maths: SURVEY.md Appendix A, GPSat/models/pure_python_gpr.py:485-498.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gpsat_kernels.h"
+
+namespace gpsat {
+namespace f64k {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+extern __shared__ __attribute__((aligned(16))) double lds_d[];
+
+#include "gpsat_opt.h"
+
+constexpr int BS = 16;         // block size
+constexpr int BLK = 256;       // doubles per block
+
+__device__ __forceinline__ int rowof(int r, int q) { return q + 4 * r; }
+
+__device__ __forceinline__ f64x4 ldg(const double* __restrict__ ws, int blk, int lane) {
+    const f64x2* p = reinterpret_cast<const f64x2*>(ws + (size_t)blk * BLK + lane * 4);
+    const f64x2 a = p[0], b = p[1];
+    f64x4 v = {a[0], a[1], b[0], b[1]};
+    return v;
+}
+
+__device__ __forceinline__ void stg(double* __restrict__ ws, int blk, int lane, const f64x4& v) {
+    f64x2* p = reinterpret_cast<f64x2*>(ws + (size_t)blk * BLK + lane * 4);
+    f64x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    p[0] = a;
+    p[1] = b;
+}
+
+__device__ __forceinline__ f64x4 ldl(int off, int lane) {
+    const f64x2* p = reinterpret_cast<const f64x2*>(lds_d + off + lane * 4);
+    const f64x2 a = p[0], b = p[1];
+    f64x4 v = {a[0], a[1], b[0], b[1]};
+    return v;
+}
+
+__device__ __forceinline__ void stl(int off, int lane, const f64x4& v) {
+    f64x2* p = reinterpret_cast<f64x2*>(lds_d + off + lane * 4);
+    f64x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    p[0] = a;
+    p[1] = b;
+}
+
+// acc += S_A^T * S_B   (4 x v_mfma_f64_16x16x4_f64)
+__device__ __forceinline__ void mma_blk(f64x4& acc, const f64x4& a, const f64x4& b) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ f64x4 zero4() { f64x4 z = {0.0, 0.0, 0.0, 0.0}; return z; }
+
+__device__ __forceinline__ double qsum(double v) {      // sum over the 4 row groups of a column (lanes g, g+16, g+32, g+48)
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int KERN>
+__device__ __forceinline__ void kfun(double r2, double& kf, double& gg) {
+    if (KERN == 0) {
+        kf = exp(-0.5 * r2);
+        gg = kf;
+    } else {
+        const double r = sqrt(fmax(r2, 1e-36));
+        if (KERN == 1) {
+            kf = exp(-r);
+            gg = kf / r;
+        } else if (KERN == 2) {
+            const double s = 1.7320508075688772 * r, e = exp(-s);
+            kf = (1.0 + s) * e;
+            gg = 3.0 * e;
+        } else {
+            const double s = 2.23606797749979 * r, e = exp(-s);
+            kf = (1.0 + s + s * s * (1.0 / 3.0)) * e;
+            gg = (5.0 / 3.0) * (1.0 + s) * e;
+        }
+    }
+}
+
+struct Lay { int xsc, y, z, alpha, Ad, LT, tmp; };   // double offsets into lds_d
+
+template <int D, int KN>
+struct Ctx {
+    Lay L;
+    double* ws;
+    int zb, dT0, vs0;
+    int N, NB, Npad, P;
+    int tid, lane, w, q, g;
+    double sf2, sn2;
+};
+
+template <int D, int KN>
+__device__ __forceinline__ f64x4 kblock(const Ctx<D, KN>& c, int bi, int bj) {
+    const int qc = BS * bj + c.g;
+    double xq[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) xq[d] = lds_d[c.L.xsc + d * c.Npad + qc];
+    f64x4 out;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int p = BS * bi + rowof(r, c.q);
+        double r2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { const double df = lds_d[c.L.xsc + d * c.Npad + p] - xq[d]; r2 = fma(df, df, r2); }
+        double kf, gg;
+        kfun<KN>(r2, kf, gg);
+        double v = ((p < c.N) && (qc < c.N)) ? c.sf2 * kf : 0.0;
+        if (p == qc) v = (p < c.N) ? (v + c.sn2) : 1.0;
+        out[r] = v;
+    }
+    return out;
+}
+
+template <int D, int KN>
+__device__ __forceinline__ f64x4 ksblock(const Ctx<D, KN>& c, int bj, const double (&xq)[D], bool qvalid) {
+    f64x4 out;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int p = BS * bj + rowof(r, c.q);
+        double r2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { const double df = lds_d[c.L.xsc + d * c.Npad + p] - xq[d]; r2 = fma(df, df, r2); }
+        double kf, gg;
+        kfun<KN>(r2, kf, gg);
+        out[r] = ((p < c.N) && qvalid) ? c.sf2 * kf : 0.0;
+    }
+    return out;
+}
+
+template <int D, int KN>
+__device__ __forceinline__ void contract(const Ctx<D, KN>& c, const f64x4& kinv, int ba, int bb, double wgt,
+                                         double (&accl)[D], double& accsf, double& accsn) {
+    const int qc = BS * bb + c.g;
+    double xq[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) xq[d] = lds_d[c.L.xsc + d * c.Npad + qc];
+    const double aq = lds_d[c.L.alpha + qc];
+    const bool qv = qc < c.N;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int p = BS * ba + rowof(r, c.q);
+        double d2[D], r2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { const double df = lds_d[c.L.xsc + d * c.Npad + p] - xq[d]; d2[d] = df * df; r2 += d2[d]; }
+        double kf, gg;
+        kfun<KN>(r2, kf, gg);
+        double Q = kinv[r] - lds_d[c.L.alpha + p] * aq;
+        Q = (qv && p < c.N) ? Q : 0.0;
+        const double wq = wgt * Q;
+        accsf = fma(wq, kf, accsf);
+        const double wg = wq * gg;
+#pragma unroll
+        for (int d = 0; d < D; ++d) accl[d] = fma(wg, d2[d], accl[d]);
+        if (p == qc) accsn += Q;
+    }
+}
+
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xffffffffull), l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), l);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// 16x16 diagonal block: W = L L^T, X = L^-1 by Gaussian elimination of [W | I] (lane i (and its mirrors) owns row i,
+// pivot row broadcast by cross-lane reads), X = D^-1/2 L1^-1.  Out: S1 = X, S2 = X^T (acc layout), logsum, bad.
+__device__ __forceinline__ void diag_factor(const f64x4& W, int Ad, int lane, f64x4& S1, f64x4& S2, double& logsum, int& bad) {
+    const int q = lane >> 4, g = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lds_d[Ad + rowof(r, q) * 17 + g] = W[r];
+    wave_lds_sync();
+    double a[16], e[16];
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) { a[cc] = lds_d[Ad + g * 17 + cc]; e[cc] = (cc == g) ? 1.0 : 0.0; }
+    int isbad = 0;
+    double mypiv = 1.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        double p = readlane_d(a[k], k);
+        if (!(p > 0.0)) { isbad = 1; p = 1.0; }
+        mypiv = (g == k) ? p : mypiv;
+        double m = a[k] / p;
+        m = (g > k) ? m : 0.0;
+#pragma unroll
+        for (int cc = k + 1; cc < 16; ++cc) a[cc] = fma(-m, readlane_d(a[cc], k), a[cc]);
+#pragma unroll
+        for (int cc = 0; cc <= k; ++cc) e[cc] = fma(-m, readlane_d(e[cc], k), e[cc]);
+    }
+    const double rs = 1.0 / sqrt(mypiv);
+    wave_lds_sync();
+    if (q == 0) {
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) lds_d[Ad + g * 17 + cc] = e[cc] * rs;     // X row-major
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        S1[r] = lds_d[Ad + rowof(r, q) * 17 + g];
+        S2[r] = lds_d[Ad + g * 17 + rowof(r, q)];
+    }
+    double lg = (lane < 16) ? 0.5 * log(mypiv) : 0.0;
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) lg += __shfl_xor(lg, off);
+    logsum = __shfl(lg, 0);
+    bad = isbad;
+}
+
+// ---- phase 1: K = U^T U by block rows, z = L^-1 y
+template <int D, int KN>
+__device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
+    Shared* sh = reinterpret_cast<Shared*>(lds_d);
+    const int NB = c.NB, lane = c.lane, w = c.w;
+    if (c.tid == 0) { sh->logdet = 0.0; sh->fail = 0; }
+    __syncthreads();
+    for (int j = 0; j < NB; ++j) {
+        if (w == 0) {
+            f64x4 Dd = zero4();
+            double tp = 0.0;
+            for (int k = 0; k < j; ++k) {
+                const f64x4 A = ldg(c.ws, k * NB + j, lane);
+                mma_blk(Dd, A, A);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tp = fma(A[r], lds_d[c.L.z + BS * k + rowof(r, c.q)], tp);
+            }
+            Dd = kblock<D, KN>(c, j, j) - Dd;
+            f64x4 S1, S2;
+            double ls;
+            int bad;
+            diag_factor(Dd, c.L.Ad, lane, S1, S2, ls, bad);
+            stg(c.ws, j * NB + j, lane, S1);
+            stg(c.ws, c.dT0 + j, lane, S2);
+            stl(c.L.LT, lane, S2);
+            const double t = qsum(tp);
+            if (c.q == 0) lds_d[c.L.tmp + c.g] = lds_d[c.L.y + BS * j + c.g] - t;
+            wave_lds_sync();
+            double zz = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zz = fma(S2[r], lds_d[c.L.tmp + rowof(r, c.q)], zz);
+            zz = qsum(zz);
+            if (c.q == 0) lds_d[c.L.z + BS * j + c.g] = zz;
+            if (lane == 0) { sh->logdet += ls; if (bad) sh->fail = 1; }
+        }
+        __syncthreads();
+        if (sh->fail) break;
+        const f64x4 Lop = ldl(c.L.LT, lane);
+        for (int i = j + 1 + w; i < NB; i += NW) {
+            f64x4 acc = zero4();
+            for (int k = 0; k < j; ++k) {
+                const f64x4 A = ldg(c.ws, k * NB + j, lane);
+                const f64x4 B = ldg(c.ws, k * NB + i, lane);
+                mma_blk(acc, A, B);
+            }
+            acc = kblock<D, KN>(c, j, i) - acc;
+            f64x4 Uo = zero4();
+            mma_blk(Uo, Lop, acc);
+            stg(c.ws, j * NB + i, lane, Uo);
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+}
+
+// ---- phase 2: M = L^-1 by block columns (one wave per column), alpha = M^T z
+template <int D, int KN>
+__device__ __forceinline__ void phase_trtri(Ctx<D, KN>& c) {
+    const int NB = c.NB, lane = c.lane;
+    for (int j0 = 0; j0 < NB; j0 += NW) {
+        const int rnd = j0 / NW;
+        const int j = j0 + ((rnd & 1) ? (NW - 1 - c.w) : c.w);
+        if (j >= NB) continue;
+        const f64x4 Mjj = ldg(c.ws, j * NB + j, lane);
+        double ap = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ap = fma(Mjj[r], lds_d[c.L.z + BS * j + rowof(r, c.q)], ap);
+        for (int i = j + 1; i < NB; ++i) {
+            f64x4 acc = zero4();
+            for (int k = j; k < i; ++k) {
+                const f64x4 A = ldg(c.ws, k * NB + i, lane);        // U_ki
+                const f64x4 B = ldg(c.ws, k * NB + j, lane);        // M_kj (k == j: diagonal slot)
+                mma_blk(acc, A, B);
+            }
+            const f64x4 Lop = ldg(c.ws, c.dT0 + i, lane);
+            f64x4 Mij = zero4();
+            mma_blk(Mij, Lop, acc);
+            Mij = -Mij;
+            stg(c.ws, i * NB + j, lane, Mij);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ap = fma(Mij[r], lds_d[c.L.z + BS * i + rowof(r, c.q)], ap);
+        }
+        const double a = qsum(ap);
+        if (c.q == 0) lds_d[c.L.alpha + BS * j + c.g] = a;
+    }
+    __syncthreads();
+}
+
+// ---- phase 3: K^-1 blocks contracted with dK/dtheta
+template <int D, int KN>
+__device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
+    Shared* sh = reinterpret_cast<Shared*>(lds_d);
+    const int NB = c.NB, lane = c.lane;
+    double accl[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) accl[d] = 0.0;
+    double accsf = 0.0, accsn = 0.0;
+    int pair = 0;
+    for (int a = 0; a < NB; ++a) {
+        for (int b = 0; b <= a; ++b, ++pair) {
+            if ((pair & (NW - 1)) != c.w) continue;
+            f64x4 acc = zero4();
+            for (int cc = a; cc < NB; ++cc) {
+                const f64x4 A = ldg(c.ws, cc * NB + a, lane);
+                const f64x4 B = ldg(c.ws, cc * NB + b, lane);
+                mma_blk(acc, A, B);
+            }
+            contract<D, KN>(c, acc, a, b, (a == b) ? 1.0 : 2.0, accl, accsf, accsn);
+        }
+    }
+    double v[D + 2];
+#pragma unroll
+    for (int d = 0; d < D; ++d) v[d] = accl[d];
+    v[D] = accsf;
+    v[D + 1] = accsn;
+#pragma unroll
+    for (int i = 0; i < D + 2; ++i) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < D + 2; ++i) sh->red[c.w][i] = v[i];
+    }
+    __syncthreads();
+    if (c.tid == 0) {
+        for (int i = 0; i < D + 2; ++i) {
+            double s = 0.0;
+            for (int ww = 0; ww < NW; ++ww) s += sh->red[ww][i];
+            if (i < D) sh->gth[i] = 0.5 * c.sf2 * s / sh->theta[i];
+            else sh->gth[i] = 0.5 * s;
+        }
+    }
+    __syncthreads();
+}
+
+template <int D, int KN>
+__device__ __forceinline__ void evaluate(Ctx<D, KN>& c, bool want_grad, const double* __restrict__ Xg) {
+    Shared* sh = reinterpret_cast<Shared*>(lds_d);
+    __syncthreads();
+    c.sf2 = sh->theta[D];
+    c.sn2 = sh->theta[D + 1];
+    for (int idx = c.tid; idx < c.Npad; idx += NT) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) lds_d[c.L.xsc + d * c.Npad + idx] = (idx < c.N) ? Xg[(size_t)idx * D + d] / sh->theta[d] : 0.0;
+    }
+    __syncthreads();
+    phase_potrf<D, KN>(c);
+    if (sh->fail) {
+        if (c.tid == 0) { sh->nll = __builtin_inf(); for (int i = 0; i < D + 2; ++i) sh->gth[i] = 0.0; }
+        __syncthreads();
+        return;
+    }
+    double qf = 0.0;
+    for (int p = c.tid; p < c.N; p += NT) { const double zz = lds_d[c.L.z + p]; qf += zz * zz; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) qf += __shfl_xor(qf, off);
+    if (c.lane == 0) sh->red[c.w][7] = qf;
+    __syncthreads();
+    if (c.tid == 0) {
+        double s = 0.0;
+        for (int ww = 0; ww < NW; ++ww) s += sh->red[ww][7];
+        sh->nll = 0.5 * s + sh->logdet + 0.5 * (double)c.N * 1.8378770664093453;
+    }
+    __syncthreads();
+    if (want_grad) {
+        phase_trtri<D, KN>(c);
+        phase_grad<D, KN>(c);
+    }
+    if (c.tid == 0) {
+        sh->n_eval += 1;
+        if (!(sh->nll == sh->nll)) sh->fail = 1;
+    }
+    __syncthreads();
+}
+
+template <int D, int KN>
+__device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const double* __restrict__ Xs, double* __restrict__ fm,
+                                             double* __restrict__ fv, double* __restrict__ yv, const double* theta) {
+    const int NB = c.NB, lane = c.lane;
+    const int PC = (c.P + BS - 1) / BS;
+    const int v0 = c.vs0 + c.w * NB;
+    for (int pc = c.w; pc < PC; pc += NW) {
+        const int qa = BS * pc + c.g;
+        const bool va = qa < c.P;
+        double xa[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) xa[d] = va ? Xs[(size_t)qa * D + d] / theta[d] : 0.0;
+        double vs = 0.0, ms = 0.0;
+        for (int j = 0; j < NB; ++j) {
+            f64x4 acc = zero4();
+            for (int k = 0; k < j; ++k) {
+                const f64x4 A = ldg(c.ws, k * NB + j, lane);
+                const f64x4 B = ldg(c.ws, v0 + k, lane);
+                mma_blk(acc, A, B);
+            }
+            const f64x4 Lop = ldg(c.ws, c.dT0 + j, lane);
+            const f64x4 Wb = ksblock<D, KN>(c, j, xa, va) - acc;
+            f64x4 V = zero4();
+            mma_blk(V, Lop, Wb);
+            stg(c.ws, v0 + j, lane, V);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                vs = fma(V[r], V[r], vs);
+                ms = fma(V[r], lds_d[c.L.z + BS * j + rowof(r, c.q)], ms);
+            }
+        }
+        vs = qsum(vs);
+        ms = qsum(ms);
+        if (c.q == 0 && va) {
+            const double var = c.sf2 - vs;
+            fm[qa] = ms; fv[qa] = var; yv[qa] = var + c.sn2;
+        }
+    }
+}
+
+template <int D, int KN>
+__global__ void __launch_bounds__(NT, 1) gp_tile_kernel_f64(const KernelArgs A) {
+    constexpr int H = D + 2;
+    Ctx<D, KN> c;
+    c.tid = threadIdx.x;
+    c.lane = c.tid & 63;
+    c.w = c.tid >> 6;
+    c.q = c.lane >> 4;
+    c.g = c.lane & 15;
+    const int NPmax = A.NBmax * BS;
+    Shared* sh = reinterpret_cast<Shared*>(lds_d);
+    int off = (int)((sizeof(Shared) + 15) / 16) * 2;
+    c.L.xsc = off; off += D * NPmax;
+    c.L.y = off; off += NPmax;
+    c.L.z = off; off += NPmax;
+    c.L.alpha = off; off += NPmax;
+    c.L.LT = off; off += BLK;
+    c.L.Ad = off; off += 16 * 17;
+    c.L.tmp = off; off += 16;
+    double* wsall = reinterpret_cast<double*>(A.ws);
+    const size_t stride = A.ws_stride;                 // doubles per workgroup
+    c.ws = wsall + (size_t)blockIdx.x * stride;
+    c.zb = (int)(stride / BLK) - 1;
+    for (int i = c.tid; i < BLK; i += NT) c.ws[(size_t)c.zb * BLK + i] = 0.0;
+    const double* X = reinterpret_cast<const double*>(A.X);
+    const double* y = reinterpret_cast<const double*>(A.y);
+    const double* Xs = reinterpret_cast<const double*>(A.Xs);
+    double* f_mean = reinterpret_cast<double*>(A.f_mean);
+    double* f_var = reinterpret_cast<double*>(A.f_var);
+    double* y_var = reinterpret_cast<double*>(A.y_var);
+    OptCfg o;
+    o.optimiser = A.optimiser; o.max_iter = A.max_iter; o.max_ls = A.max_ls; o.want_grad_out = A.grad != nullptr;
+    o.ftol = A.ftol; o.gtol = A.gtol; o.adam_lr = A.adam_lr;
+
+    for (;;) {
+        __syncthreads();
+        if (c.tid == 0) sh->tile = atomicAdd(A.queue, 1);
+        __syncthreads();
+        const int slot = sh->tile;
+        if (slot >= A.T) break;
+        const int t = A.order[slot];
+        const long long o0 = A.obs_off[t], o1 = A.obs_off[t + 1];
+        const long long p0 = A.pred_off[t], p1 = A.pred_off[t + 1];
+        c.N = (int)(o1 - o0);
+        c.P = (int)(p1 - p0);
+        c.NB = (c.N + BS - 1) / BS;
+        c.Npad = c.NB * BS;
+        const int NB = c.NB;
+        c.dT0 = NB * NB;
+        c.vs0 = c.dT0 + NB;
+        if (c.N == 0) {
+            if (c.tid == 0) {
+                A.status[t] = 4; A.n_eval[t] = 0; A.nll[t] = 0.0;
+                for (int i = 0; i < H; ++i) {
+                    A.theta[(size_t)t * H + i] = A.theta0[(size_t)t * H + i];
+                    if (A.grad) A.grad[(size_t)t * H + i] = 0.0;
+                }
+            }
+            for (long long qq = p0 + c.tid; qq < p1; qq += NT) {
+                const double sf2 = A.theta0[(size_t)t * H + D], sn2 = A.theta0[(size_t)t * H + D + 1];
+                f_mean[qq] = 0.0; f_var[qq] = sf2; y_var[qq] = sf2 + sn2;
+            }
+            continue;
+        }
+        for (int idx = c.tid; idx < c.Npad; idx += NT) {
+            lds_d[c.L.y + idx] = (idx < c.N) ? y[o0 + idx] : 0.0;
+            lds_d[c.L.z + idx] = 0.0;
+            lds_d[c.L.alpha + idx] = 0.0;
+        }
+        if (c.tid == 0) {
+            sh->n_eval = 0; sh->n_eval_opt = 0; sh->status = 5; sh->iter = 0; sh->hist_n = 0; sh->hist_pos = 0;
+            sh->last_dec = 1e300;
+            sh->fail = 0;
+            for (int i = 0; i < H; ++i) {
+                const double lo = A.lo[(size_t)t * H + i], hi = A.hi[(size_t)t * H + i];
+                const bool box = (lo == lo) && (hi == hi) && (fabs(lo) < 1e300) && (fabs(hi) < 1e300);
+                sh->box[i] = box ? 1 : 0;
+                sh->lo[i] = lo; sh->hi[i] = hi;
+                sh->shift[i] = (!box && i == D + 1) ? 1e-6 : 0.0;
+                sh->trainable[i] = A.trainable[i] ? 1 : 0;
+                sh->theta[i] = A.theta0[(size_t)t * H + i];
+                sh->u[i] = u_of_theta(sh, i, sh->theta[i]);
+                sh->m1[i] = 0.0; sh->m2[i] = 0.0;
+            }
+            const bool optim = (o.optimiser != 0 && o.max_iter > 0);
+            sh->phase = optim ? PH_INIT : PH_FINAL;
+            sh->want_grad = optim ? 1 : o.want_grad_out;
+        }
+        __syncthreads();
+        for (;;) {
+            evaluate<D, KN>(c, sh->want_grad != 0, X + (size_t)o0 * D);
+            if (c.tid == 0) opt_advance(sh, H, o);
+            __syncthreads();
+            if (sh->phase == PH_EXIT) break;
+        }
+        if (c.tid == 0) {
+            int st = sh->status;
+            if (sh->fail) st = (sh->nll == sh->nll) ? 2 : 3;
+            A.status[t] = st;
+            A.n_eval[t] = sh->n_eval_opt;
+            A.nll[t] = sh->fail ? __builtin_nan("") : sh->nll;
+            for (int i = 0; i < H; ++i) {
+                A.theta[(size_t)t * H + i] = sh->theta[i];
+                if (A.grad) A.grad[(size_t)t * H + i] = sh->fail ? __builtin_nan("") : sh->gth[i];
+            }
+        }
+        if (c.P > 0) {
+            if (!sh->fail) {
+                predict_tile<D, KN>(c, Xs + (size_t)p0 * D, f_mean + p0, f_var + p0, y_var + p0, sh->theta);
+            } else {
+                for (long long qq = p0 + c.tid; qq < p1; qq += NT) {
+                    f_mean[qq] = __builtin_nan(""); f_var[qq] = __builtin_nan(""); y_var[qq] = __builtin_nan("");
+                }
+            }
+        }
+    }
+}
+
+template <int D, int KN>
+static hipError_t launch_one(const KernelArgs& a, int grid, size_t smem, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gp_tile_kernel_f64<D, KN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((gp_tile_kernel_f64<D, KN>), dim3(grid), dim3(NT), smem, stream, a);
+    return hipGetLastError();
+}
+
+template <int D>
+static hipError_t launch_d(const KernelArgs& a, int grid, size_t smem, hipStream_t stream) {
+    switch (a.kernel) {
+        case 0: return launch_one<D, 0>(a, grid, smem, stream);
+        case 1: return launch_one<D, 1>(a, grid, smem, stream);
+        case 2: return launch_one<D, 2>(a, grid, smem, stream);
+        case 3: return launch_one<D, 3>(a, grid, smem, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace f64k
+
+size_t shared_bytes_f64(int D, int NBmax) {
+    const size_t NP = (size_t)NBmax * f64k::BS;
+    const size_t dbl = (sizeof(f64k::Shared) + 15) / 16 * 2 + D * NP + 3 * NP + f64k::BLK + 16 * 17 + 16 + 2;
+    return (dbl * sizeof(double) + 15) & ~size_t(15);
+}
+
+size_t workspace_doubles_per_wg_f64(int NBmax) {
+    return (size_t)f64k::BLK * ((size_t)NBmax * NBmax + (size_t)NBmax + (size_t)f64k::NW * NBmax + 1);
+}
+
+hipError_t launch_tiles_f64(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream) {
+    switch (D) {
+        case 1: return f64k::launch_d<1>(a, grid, smem, stream);
+        case 2: return f64k::launch_d<2>(a, grid, smem, stream);
+        case 3: return f64k::launch_d<3>(a, grid, smem, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace gpsat

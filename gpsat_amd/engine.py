@@ -66,12 +66,14 @@ class Engine:
 
     def fit_predict_batch(self, *, D, obs_off, X, y, pred_off, Xs, theta0, lo=None, hi=None,
                           trainable=None, kernel="Matern32", optimiser="lbfgs", max_iter=10_000,
-                          max_ls=20, ftol=0.0, gtol=0.0, adam_lr=0.0, want_grad=False,
-                          out=None) -> BatchResult:
+                          max_ls=0, ftol=0.0, gtol=0.0, adam_lr=0.0, want_grad=False,
+                          out=None, dtype="f32") -> BatchResult:
         """
-        X [sumN, D], y [sumN], Xs [sumP, D]: float32 numpy arrays (host mode) or torch.cuda float32
-        tensors (device mode; outputs are then torch tensors, optionally preallocated via ``out``=
-        (f_mean, f_var, y_var)).  Offsets / theta0 / bounds are always host numpy.
+        X [sumN, D], y [sumN], Xs [sumP, D]: numpy arrays (host mode) or contiguous torch.cuda tensors (device
+        mode; outputs are then torch tensors, optionally preallocated via ``out`` = (f_mean, f_var, y_var)).
+        ``dtype``: "f32" (default; fp32 MFMA kernels) or "f64" (the reference's native precision, fp64 MFMA
+        kernels); host arrays are cast, device tensors must already have that dtype.  Offsets / theta0 / bounds
+        are always host numpy (fp64).
         """
         obs_off = np.ascontiguousarray(obs_off, dtype=np.int64)
         pred_off = np.ascontiguousarray(pred_off, dtype=np.int64)
@@ -88,17 +90,21 @@ class Engine:
         assert trainable.shape == (H,)
         sumN, sumP = int(obs_off[-1]), int(pred_off[-1])
 
+        if dtype not in ("f32", "f64"):
+            raise GpsatError(f"dtype {dtype!r}: use 'f32' or 'f64'")
+        np_dt = np.float32 if dtype == "f32" else np.float64
         device_mode = not isinstance(X, np.ndarray)
         if device_mode:
             import torch
+            t_dt = torch.float32 if dtype == "f32" else torch.float64
             for tname, t_ in (("X", X), ("y", y), ("Xs", Xs)):
-                if not (isinstance(t_, torch.Tensor) and t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous()):
-                    raise GpsatError(f"{tname}: device mode needs contiguous float32 CUDA tensors")
+                if not (isinstance(t_, torch.Tensor) and t_.is_cuda and t_.dtype == t_dt and t_.is_contiguous()):
+                    raise GpsatError(f"{tname}: device mode needs contiguous {dtype} CUDA tensors")
             if X.device.index != self.device_id:
                 raise GpsatError(f"tensors live on cuda:{X.device.index}, engine on device {self.device_id}")
             assert X.numel() == sumN * D and y.numel() == sumN and Xs.numel() == sumP * D
             if out is None:
-                fm = torch.empty(max(sumP, 1), dtype=torch.float32, device=X.device)
+                fm = torch.empty(max(sumP, 1), dtype=t_dt, device=X.device)
                 fv = torch.empty_like(fm)
                 yv = torch.empty_like(fm)
             else:
@@ -107,12 +113,12 @@ class Engine:
             pX, py, pXs = X.data_ptr(), y.data_ptr(), Xs.data_ptr()
             pfm, pfv, pyv = fm.data_ptr(), fv.data_ptr(), yv.data_ptr()
         else:
-            X = np.ascontiguousarray(X, dtype=np.float32).reshape(sumN, D)
-            y = np.ascontiguousarray(y, dtype=np.float32).reshape(sumN)
-            Xs = np.ascontiguousarray(Xs, dtype=np.float32).reshape(sumP, D)
-            fm = np.empty(sumP, dtype=np.float32)
-            fv = np.empty(sumP, dtype=np.float32)
-            yv = np.empty(sumP, dtype=np.float32)
+            X = np.ascontiguousarray(X, dtype=np_dt).reshape(sumN, D)
+            y = np.ascontiguousarray(y, dtype=np_dt).reshape(sumN)
+            Xs = np.ascontiguousarray(Xs, dtype=np_dt).reshape(sumP, D)
+            fm = np.empty(sumP, dtype=np_dt)
+            fv = np.empty(sumP, dtype=np_dt)
+            yv = np.empty(sumP, dtype=np_dt)
             pX, py, pXs = _ptr(X), _ptr(y), _ptr(Xs)
             pfm, pfv, pyv = _ptr(fm), _ptr(fv), _ptr(yv)
 
@@ -123,7 +129,7 @@ class Engine:
         n_eval = np.empty(T, dtype=np.int32)
 
         b = L.GpsatBatch()
-        b.T, b.D, b.dtype = T, D, L.F32
+        b.T, b.D, b.dtype = T, D, (L.F32 if dtype == "f32" else L.F64)
         b.kernel = L.KERNEL_IDS[kernel] if isinstance(kernel, str) else int(kernel)
         b.memory = L.MEM_DEVICE if device_mode else L.MEM_HOST
         b.optimiser = L.OPT_IDS[optimiser] if not isinstance(optimiser, int) else optimiser

@@ -56,7 +56,7 @@ class HipGPRModel:
     def __init__(self, data=None, coords_col=None, obs_col=None, coords=None, obs=None,
                  coords_scale=None, obs_scale=None, obs_mean=None, verbose=True, *,
                  kernel="Matern32", kernel_kwargs=None, mean_function=None, mean_func_kwargs=None,
-                 noise_variance=None, likelihood=None, engine=None, **kwargs):
+                 noise_variance=None, likelihood=None, engine=None, dtype="f32", **kwargs):
         # ---- data intake: GPSat/models/base_model.py:134-189
         if data is not None:
             assert coords_col is not None, "data was provided, but coord_col was not"
@@ -123,6 +123,9 @@ class HipGPRModel:
         if mean_function is not None or likelihood is not None:
             raise NotImplementedError("mean_function / custom likelihood are not built in the HIP backend")
         self.kernel = kernel
+        if dtype not in ("f32", "f64"):
+            raise ValueError("dtype must be 'f32' or 'f64'")
+        self.dtype = dtype                                # device compute precision (the reference computes in fp64)
         D = self.coords.shape[1]
         if D > 3:
             raise NotImplementedError("HIP backend is built for 1..3 input dimensions")
@@ -267,9 +270,9 @@ class HipGPRModel:
     def _run(self, *, optimiser, max_iter=0, pred_coords=None, **opt_kwargs):
         N, D = self.coords.shape
         P = 0 if pred_coords is None else len(pred_coords)
-        Xs = np.zeros((0, D), dtype=np.float32) if pred_coords is None else pred_coords.astype(np.float32)
+        Xs = np.zeros((0, D)) if pred_coords is None else pred_coords
         return self._engine.fit_predict_batch(
-            D=D, obs_off=np.array([0, N]), X=self.coords.astype(np.float32), y=self.obs[:, 0].astype(np.float32),
+            dtype=self.dtype, D=D, obs_off=np.array([0, N]), X=self.coords, y=self.obs[:, 0],
             pred_off=np.array([0, P]), Xs=Xs, theta0=self._theta[None, :], lo=self._lo[None, :],
             hi=self._hi[None, :], trainable=self._trainable, kernel=self.kernel, optimiser=optimiser,
             max_iter=max_iter, **opt_kwargs)

@@ -94,14 +94,14 @@ typedef struct gpsat_batch {
     /* ---- shape ---- */
     int32_t T;                 /* number of tiles                                           */
     int32_t D;                 /* input dimension (1..3 in this build)                      */
-    int32_t dtype;             /* GPSAT_F32 (GPSAT_F64: not built yet -> GPSAT_EINVAL)      */
+    int32_t dtype;             /* GPSAT_F32 (fp32 MFMA kernels) | GPSAT_F64 (fp64 MFMA kernels) */
     int32_t kernel;            /* GPSAT_KERNEL_*                                            */
     int32_t memory;            /* GPSAT_MEM_HOST / GPSAT_MEM_DEVICE for the bulk arrays      */
     int32_t optimiser;         /* GPSAT_OPT_*                                               */
     int32_t max_iter;          /* optimiser iteration limit (scipy options.maxiter)         */
-    int32_t max_ls;            /* max line-search evaluations per iteration (0 = 10)        */
-    double  ftol;              /* relative objective decrease tolerance (0 = default 1e-6,   */
-                               /*   the fp32 analogue of SciPy's factr*eps = 2.2e-9 in fp64) */
+    int32_t max_ls;            /* max line-search evaluations per iteration (0 = 10; fp64: 20) */
+    double  ftol;              /* relative objective decrease tolerance (0 = default: fp64   */
+                               /*   2.2e-9 = SciPy's factr*eps, fp32 1e-6 = its fp32 analogue) */
     double  gtol;              /* max-norm gradient tolerance in u-space (0 = default 1e-5) */
     double  adam_lr;           /* Adam learning rate (0 = default 0.1)                      */
 
