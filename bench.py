@@ -157,7 +157,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)   # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -173,7 +174,7 @@ def main():
         r = eng.fit_predict_batch(D=D, obs_off=obs_off, X=dX, y=dy, pred_off=pred_off, Xs=dXs, theta0=theta0,
                                   lo=lo, hi=hi, kernel=a.kernel, optimiser=a.optimiser, max_iter=a.max_iter,
                                   out=(fm, fv, yv))
-        if world > 1:
+        if use_dist:
             # final gather of per-tile hyper-parameters + predictions (the only collective of the path)
             fixed = torch.from_numpy(np.concatenate([r.theta, r.nll[:, None], r.status[:, None].astype(np.float64),
                                                      r.n_eval[:, None].astype(np.float64)], axis=1)).to(dev)
@@ -181,7 +182,7 @@ def main():
         return r
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -197,7 +198,7 @@ def main():
         statuses = r.status
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -228,7 +229,7 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     eng.close()
 
