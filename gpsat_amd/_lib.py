@@ -22,7 +22,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 STATUS = {0: "converged", 1: "max_iter", 2: "not_pd", 3: "nan", 4: "skipped", 5: "not_optimised"}
 
 EXPORTS = ["gpsat_version", "gpsat_last_error", "gpsat_device_count", "gpsat_create", "gpsat_device_name",
-           "gpsat_destroy", "gpsat_fit_predict_batch", "gpsat_last_timing"]
+           "gpsat_destroy", "gpsat_fit_predict_batch", "gpsat_last_timing", "gpsat_select_batch"]
 
 
 class GpsatOpts(C.Structure):
@@ -40,6 +40,16 @@ class GpsatBatch(C.Structure):
         ("theta", C.c_void_p), ("nll", C.c_void_p), ("grad", C.c_void_p), ("status", C.c_void_p),
         ("n_eval", C.c_void_p), ("f_mean", C.c_void_p), ("f_var", C.c_void_p), ("y_var", C.c_void_p),
     ]
+
+
+SEL_MAXCRIT = 4
+COMP_IDS = {">=": 0, ">": 1, "==": 2, "<": 3, "<=": 4}
+
+
+class GpsatSelectSpec(C.Structure):
+    _fields_ = [("n_crit", C.c_int32), ("kind", C.c_int32 * SEL_MAXCRIT), ("comp", C.c_int32 * SEL_MAXCRIT),
+                ("ncols", C.c_int32 * SEL_MAXCRIT), ("cols", (C.c_int32 * 3) * SEL_MAXCRIT),
+                ("val", C.c_double * SEL_MAXCRIT)]
 
 
 class LibraryMissing(ImportError):
@@ -66,6 +76,9 @@ def load():
     lib.gpsat_destroy.argtypes = [C.c_void_p]
     lib.gpsat_fit_predict_batch.restype = C.c_int
     lib.gpsat_fit_predict_batch.argtypes = [C.c_void_p, C.POINTER(GpsatBatch)]
+    lib.gpsat_select_batch.restype = C.c_int
+    lib.gpsat_select_batch.argtypes = [C.c_void_p, C.POINTER(GpsatSelectSpec), C.c_int64, C.c_int32, C.c_void_p, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     lib.gpsat_last_timing.restype = C.c_int
     lib.gpsat_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     if lib.gpsat_version() != ABI_VERSION:

@@ -60,6 +60,7 @@ struct gpsat_handle {
     double last_kernel_ms = 0.0, last_total_ms = 0.0;
     // device buffers (grown lazily, owned by the handle)
     DevBuf meta_i64, meta_f64, meta_misc, out_f64, out_i32, bulk_in, bulk_out, ws, prof;
+    DevBuf sel_pts, sel_refs, sel_cnt, sel_idx;
     unsigned long long prof_host[64] = {0};
 };
 
@@ -112,6 +113,7 @@ int gpsat_destroy(gpsat_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->meta_i64.release(); h->meta_f64.release(); h->meta_misc.release(); h->out_f64.release();
     h->out_i32.release(); h->bulk_in.release(); h->bulk_out.release(); h->ws.release(); h->prof.release();
+    h->sel_pts.release(); h->sel_refs.release(); h->sel_cnt.release(); h->sel_idx.release();
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -267,6 +269,86 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     float km = 0.f, tm = 0.f;
     HIP_TRY(hipEventElapsedTime(&km, h->ev[1], h->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&tm, h->ev[0], h->ev[3]));
+    h->last_kernel_ms = km;
+    h->last_total_ms = tm;
+    return GPSAT_OK;
+}
+
+int gpsat_select_batch(gpsat_handle* h, const gpsat_select_spec* sp, int64_t M, int32_t C, const double* points,
+                       int32_t T, const double* refs, int64_t* off, int32_t* idx, int64_t capacity) {
+    if (!h || !sp || !off) return fail(GPSAT_EINVAL, "gpsat_select_batch: NULL argument");
+    if (T < 0 || M < 0 || C < 1) return fail(GPSAT_EINVAL, "gpsat_select_batch: bad sizes");
+    if (M > 2147483647LL) return fail(GPSAT_EINVAL, "gpsat_select_batch: more than 2^31-1 rows");
+    if (sp->n_crit < 1 || sp->n_crit > GPSAT_SEL_MAXCRIT) return fail(GPSAT_EINVAL, "gpsat_select_batch: n_crit out of range");
+    gpsat::SelectArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.n_crit = sp->n_crit;
+    for (int k = 0; k < sp->n_crit; ++k) {
+        if (sp->kind[k] != 0 && sp->kind[k] != 1) return fail(GPSAT_EINVAL, "gpsat_select_batch: bad criterion kind");
+        if (sp->comp[k] < 0 || sp->comp[k] > 4) return fail(GPSAT_EINVAL, "gpsat_select_batch: bad comparison");
+        const int nc = sp->kind[k] == 0 ? 1 : sp->ncols[k];
+        if (nc < 1 || nc > 3) return fail(GPSAT_EINVAL, "gpsat_select_batch: ball criteria take 1..3 columns");
+        if (sp->kind[k] == 1 && sp->comp[k] != 3 && sp->comp[k] != 4) return fail(GPSAT_EINVAL, "gpsat_select_batch: ball criteria are < or <=");
+        a.kind[k] = sp->kind[k]; a.comp[k] = sp->comp[k]; a.ncols[k] = nc; a.val[k] = sp->val[k];
+        for (int m = 0; m < nc; ++m) {
+            if (sp->cols[k][m] < 0 || sp->cols[k][m] >= C) return fail(GPSAT_EINVAL, "gpsat_select_batch: column index out of range");
+            a.cols[k][m] = sp->cols[k][m];
+        }
+    }
+    off[0] = 0;
+    if (T == 0) return GPSAT_OK;
+    if ((M > 0 && !points) || !refs) return fail(GPSAT_EINVAL, "gpsat_select_batch: NULL table");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc;
+    if ((rc = h->sel_pts.reserve(std::max<size_t>((size_t)M * C, 1) * sizeof(double)))) return rc;
+    if ((rc = h->sel_refs.reserve((size_t)T * C * sizeof(double)))) return rc;
+    // row chunks: enough workgroups to fill the chip (T/32 workgroups per chunk), chunk a multiple of 64 rows
+    const int wgs_per_chunk = std::max(1, (T + 31) / 32);
+    int n_chunks = (int)std::min<long long>(std::max<long long>(1, (4096 + wgs_per_chunk - 1) / wgs_per_chunk), std::max<long long>(1, (M + 4095) / 4096));
+    long long chunk_rows = ((M + n_chunks - 1) / n_chunks + 63) / 64 * 64;
+    if (chunk_rows < 64) chunk_rows = 64;
+    n_chunks = (int)std::max<long long>(1, (M + chunk_rows - 1) / chunk_rows);
+    const size_t ncell = (size_t)T * n_chunks;
+    if ((rc = h->sel_cnt.reserve(2 * ncell * sizeof(long long)))) return rc;
+    if (M > 0) HIP_TRY(hipMemcpyAsync(h->sel_pts.p, points, (size_t)M * C * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->sel_refs.p, refs, (size_t)T * C * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    a.M = M; a.C = C; a.T = T;
+    a.n_chunks = n_chunks; a.chunk_rows = chunk_rows;
+    a.pts = static_cast<const double*>(h->sel_pts.p);
+    a.refs = static_cast<const double*>(h->sel_refs.p);
+    a.counts = static_cast<long long*>(h->sel_cnt.p);
+    HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+    HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+    HIP_TRY(gpsat::launch_select(a, false, h->stream));
+    std::vector<long long> cnt(ncell);
+    HIP_TRY(hipMemcpyAsync(cnt.data(), a.counts, ncell * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    // exclusive scan over (expert, chunk) cells, expert-major: cnt becomes the start offset of every cell
+    long long run = 0;
+    for (int t = 0; t < T; ++t) {
+        off[t] = run;
+        for (int cc = 0; cc < n_chunks; ++cc) { const long long v = cnt[(size_t)t * n_chunks + cc]; cnt[(size_t)t * n_chunks + cc] = run; run += v; }
+    }
+    off[T] = run;
+    if (!idx) return GPSAT_OK;
+    if (capacity < off[T]) return fail(GPSAT_EINVAL, "gpsat_select_batch: idx capacity too small (see off[T])");
+    if (off[T] > 0) {
+        if ((rc = h->sel_idx.reserve((size_t)off[T] * sizeof(int)))) return rc;
+        long long* d_off = static_cast<long long*>(h->sel_cnt.p) + ncell;
+        HIP_TRY(hipMemcpyAsync(d_off, cnt.data(), ncell * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+        a.off = d_off;
+        a.idx = static_cast<int*>(h->sel_idx.p);
+        HIP_TRY(gpsat::launch_select(a, true, h->stream));
+        HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+        HIP_TRY(hipMemcpyAsync(idx, a.idx, (size_t)off[T] * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    } else {
+        HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+    }
+    HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float km = 0.f, tm = 0.f;
+    HIP_TRY(hipEventElapsedTime(&km, h->ev[1], h->ev[2]));      // count + scan round trip + fill
     HIP_TRY(hipEventElapsedTime(&tm, h->ev[0], h->ev[3]));
     h->last_kernel_ms = km;
     h->last_total_ms = tm;

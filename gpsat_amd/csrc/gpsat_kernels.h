@@ -42,5 +42,29 @@ hipError_t launch_tiles_f64(int D, const KernelArgs& a, int grid, size_t smem, h
 size_t workspace_floats_per_wg(int NBmax);
 hipError_t launch_tiles(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream);
 
+#define GPSAT_SEL_MAXCRIT 4
+
+// tile selection (gpsat_select.hip); all pointers are device pointers
+struct SelectArgs {
+    int n_crit;
+    int kind[GPSAT_SEL_MAXCRIT];      // 0: 1-D compare, 1: Euclidean ball
+    int comp[GPSAT_SEL_MAXCRIT];      // 0 >=, 1 >, 2 ==, 3 <, 4 <=
+    int ncols[GPSAT_SEL_MAXCRIT];
+    int cols[GPSAT_SEL_MAXCRIT][3];
+    double val[GPSAT_SEL_MAXCRIT];
+    long long M;                      // rows of the point table
+    int C;                            // columns of the point table / reference table
+    int T;                            // experts
+    const double* pts;                // [C][M] column-major (SoA)
+    const double* refs;               // [T][C] row-major
+    int n_chunks;                     // row chunks (grid.y)
+    long long chunk_rows;             // rows per chunk (multiple of 64)
+    long long* counts;                // [T][n_chunks]   (count pass)
+    const long long* off;             // [T][n_chunks] start offsets (fill pass)
+    int* idx;                         // [off[T]] (fill pass)
+};
+
+hipError_t launch_select(const SelectArgs& a, bool fill, hipStream_t stream);
+
 }  // namespace gpsat
 #endif

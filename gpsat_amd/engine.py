@@ -152,6 +152,44 @@ class Engine:
                            grad=grad, kernel_ms=km.value, total_ms=tm.value)
 
 
+    def select_batch(self, points: np.ndarray, refs: np.ndarray, criteria):
+        """Batched tile selection on the GPU (gpsat_select_batch).
+
+        points [M, C] fp64, refs [T, C] fp64 (same column numbering); criteria: list of
+        ("cmp", col, comp, val)  ->  points[:, col] <comp> refs[:, col] + val
+        ("ball", [cols], comp, r) -> Euclidean ball, comp "<=" (inclusive) or "<" (strict).
+        Returns (off [T+1] int64, idx [off[-1]] int32): selected rows per expert in source order."""
+        points = np.asarray(points, dtype=np.float64)
+        refs = np.ascontiguousarray(refs, dtype=np.float64)
+        M, Cc = points.shape
+        T = refs.shape[0]
+        assert refs.shape[1] == Cc
+        pts_cm = np.ascontiguousarray(points.T)                       # column-major [C][M]
+        sp = L.GpsatSelectSpec()
+        if not 1 <= len(criteria) <= L.SEL_MAXCRIT:
+            raise GpsatError(f"1..{L.SEL_MAXCRIT} criteria supported")
+        sp.n_crit = len(criteria)
+        for k, (kind, cols, comp, val) in enumerate(criteria):
+            sp.kind[k] = 0 if kind == "cmp" else 1
+            sp.comp[k] = L.COMP_IDS[comp]
+            cl = [cols] if kind == "cmp" else list(cols)
+            sp.ncols[k] = len(cl)
+            for m_, c_ in enumerate(cl):
+                sp.cols[k][m_] = int(c_)
+            sp.val[k] = float(val)
+        off = np.zeros(T + 1, dtype=np.int64)
+        rc = self._lib.gpsat_select_batch(self._h, C.byref(sp), M, Cc, _ptr(pts_cm), T, _ptr(refs), _ptr(off), None, 0)
+        if rc != 0:
+            raise GpsatError(f"gpsat_select_batch failed ({rc}): {self._lib.gpsat_last_error().decode()}")
+        idx = np.empty(int(off[-1]), dtype=np.int32)
+        if len(idx):
+            rc = self._lib.gpsat_select_batch(self._h, C.byref(sp), M, Cc, _ptr(pts_cm), T, _ptr(refs), _ptr(off),
+                                              _ptr(idx), len(idx))
+            if rc != 0:
+                raise GpsatError(f"gpsat_select_batch failed ({rc}): {self._lib.gpsat_last_error().decode()}")
+        return off, idx
+
+
 _default_engine = None
 
 

@@ -111,6 +111,42 @@ class LocalSelector:
         return select
 
 
+class DeviceSelector:
+    """The same membership as ``LocalSelector`` / ``max_dist_bool`` for ALL reference locations in one GPU call
+    (``gpsat_select_batch``: fp64 predicates with the reference's arithmetic, bit-exact, source row order).
+
+    ``local_select`` entries as in the reference; ``strict_ball=True`` gives the prediction-location semantics
+    (strict ``<`` on the squared distance, GPSat/prediction_locations.py:37,43)."""
+
+    def __init__(self, df: pd.DataFrame, local_select: List[dict], engine, strict_ball: bool = False):
+        self.engine = engine
+        cols = []
+        for ls in local_select:
+            for c_ in ([ls["col"]] if isinstance(ls["col"], str) else list(ls["col"])):
+                assert c_ in df, f"column: {c_} is not in df.columns: {df.columns}"
+                if c_ not in cols:
+                    cols.append(c_)
+        self.cols = cols
+        self.points = df.loc[:, cols].values.astype(np.float64)
+        self.criteria = []
+        for ls in local_select:
+            if isinstance(ls["col"], str):
+                assert ls["comp"] in _COMPS, f"comp: {ls['comp']} is not valid"
+                self.criteria.append(("cmp", cols.index(ls["col"]), ls["comp"], ls["val"]))
+            else:
+                assert ls["comp"] in ["<", "<="], "for multi dimensional values only less than comparison handled"
+                if len(ls["col"]) > 3:
+                    raise NotImplementedError("device ball selection takes 1..3 columns")
+                self.criteria.append(("ball", [cols.index(c_) for c_ in ls["col"]], "<" if strict_ball else "<=", ls["val"]))
+
+    def select(self, refs: pd.DataFrame):
+        """refs: one row per expert with (at least) the columns used by the criteria.
+        Returns CSR (off [T+1], idx [off[-1]]) of selected row POSITIONS of the frame, ascending per expert."""
+        for c_ in self.cols:
+            assert c_ in refs, f"col: {c_} is not in reference_location - {list(refs.columns)}"
+        return self.engine.select_batch(self.points, refs.loc[:, self.cols].values.astype(np.float64), self.criteria)
+
+
 def max_dist_bool(loc: np.ndarray, ref_loc: np.ndarray, max_dist: float) -> np.ndarray:
     """``_max_dist_bool`` (GPSat/prediction_locations.py:18-43): per-dimension pre-filter, then the STRICT test
     sum((loc - ref)^2) < max_dist^2, in fp64."""
@@ -209,7 +245,7 @@ def get_results(store_path: str) -> Dict[str, pd.DataFrame]:
 # ----------------------------------------------------------------------------------------------------------
 class BatchedLocalExpertOI:
     def __init__(self, expert_loc_config: dict, data_config: dict, model_config: dict, pred_loc_config: dict,
-                 engine=None):
+                 engine=None, device_select: bool = False):
         self.config = {"locations": _jsonable(expert_loc_config), "data": _jsonable(data_config),
                        "model": _jsonable(model_config), "pred_loc": _jsonable(pred_loc_config)}
         # ---- data (local_experts.py:266-290)
@@ -253,6 +289,8 @@ class BatchedLocalExpertOI:
         self.pred_loc = PredictionLocations(coords_col=self.coords_col, **plc)
         from .engine import default_engine
         self.engine = engine if engine is not None else default_engine()
+        # tile membership for all experts in one GPU call (bit-identical to the host selector)
+        self.device_select = device_select
 
     # -- per-tile host-side model logic reuses the drop-in class (intake, scaling, defaults, constraints)
     def _host_model(self, df_local):
@@ -307,6 +345,9 @@ class BatchedLocalExpertOI:
             keys = [tuple(r) if len(cc) > 1 else r[0] for r in xl[cc].values.tolist()]
             todo = np.array([k not in have for k in keys])
         selector = LocalSelector(self.df, self.local_select)
+        dev_off = dev_idx = None
+        if self.device_select and len(self.local_select):
+            dev_off, dev_idx = DeviceSelector(self.df, self.local_select, self.engine).select(xl)
         D = len(cc)
         kernel = self.init_params.get("kernel", "Matern32")
         if kernel not in L.KERNEL_IDS:
@@ -325,7 +366,8 @@ class BatchedLocalExpertOI:
             pc = self.pred_loc(loc)
             if len(pc) == 0:                                   # local_experts.py:962-965: skipped, nothing stored
                 continue
-            df_local = self.df.loc[selector.mask(ref)]
+            df_local = self.df.iloc[dev_idx[dev_off[i]:dev_off[i + 1]]] if dev_idx is not None \
+                else self.df.loc[selector.mask(ref)]
             if len(df_local) < min_obs:                        # local_experts.py:988-1012: stub run_details row
                 stubs.append((loc, len(df_local)))
                 continue

@@ -154,6 +154,34 @@ int gpsat_destroy(gpsat_handle *h);
 int gpsat_fit_predict_batch(gpsat_handle *h, const gpsat_batch *b);
 
 /*
+ * Batched tile selection: which rows of a point table belong to each of T expert tiles.
+ * Replaces DataLoader.local_data_select (GPSat/dataloader.py:2352-2447) and the max_dist filter of
+ * PredictionLocations (GPSat/prediction_locations.py:18-43) for all experts at once, in fp64 with the reference's
+ * comparison arithmetic (bit-exact membership, source row order).
+ *   kind 0: points[cols[k][0]] <comp> (refs[cols[k][0]] + val[k])       comp: 0 >=, 1 >, 2 ==, 3 <, 4 <=
+ *   kind 1: sum_m (points[cols[k][m]] - refs[cols[k][m]])^2 <= val[k]^2  (comp 4, observations: inclusive ball)
+ *                                                          <  val[k]^2  (comp 3, prediction locations: strict)
+ */
+#define GPSAT_SEL_MAXCRIT 4
+typedef struct gpsat_select_spec {
+    int32_t n_crit;                        /* 1 .. GPSAT_SEL_MAXCRIT criteria, ANDed                 */
+    int32_t kind[GPSAT_SEL_MAXCRIT];
+    int32_t comp[GPSAT_SEL_MAXCRIT];
+    int32_t ncols[GPSAT_SEL_MAXCRIT];      /* kind 1: 1..3 columns                                   */
+    int32_t cols[GPSAT_SEL_MAXCRIT][3];    /* column indices (same numbering in points and refs)      */
+    double  val[GPSAT_SEL_MAXCRIT];
+} gpsat_select_spec;
+
+/*
+ * points: host, column-major [C][M] fp64;  refs: host, row-major [T][C] fp64.
+ * off  : host out [T+1] CSR offsets (always written).
+ * idx  : host out [capacity] selected row indices per expert, ascending; may be NULL (count only).
+ * Returns GPSAT_EINVAL if capacity < off[T] (off is still valid: call again with a larger buffer).
+ */
+int gpsat_select_batch(gpsat_handle *h, const gpsat_select_spec *spec, int64_t M, int32_t C, const double *points,
+                       int32_t T, const double *refs, int64_t *off, int32_t *idx, int64_t capacity);
+
+/*
  * Timing of the last gpsat_fit_predict_batch on this handle, measured with HIP events on the
  * handle's stream: kernel_ms = the persistent tile kernel alone, total_ms = H2D + kernel + D2H.
  */

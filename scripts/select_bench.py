@@ -1,0 +1,25 @@
+"""Developer: throughput of the batched tile selection (T experts x M rows), device vs host (KD-tree + compares)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, pandas as pd
+from gpsat_amd.engine import Engine
+from gpsat_amd.local_experts import DeviceSelector, LocalSelector
+rng = np.random.default_rng(0)
+M, T = int(os.environ.get("M", 1_000_000)), int(os.environ.get("T", 4096))
+df = pd.DataFrame({"x": rng.uniform(-3e6, 3e6, M), "y": rng.uniform(-3e6, 3e6, M), "t": rng.integers(0, 30, M).astype(float)})
+xl = pd.DataFrame({"x": rng.uniform(-2.5e6, 2.5e6, T), "y": rng.uniform(-2.5e6, 2.5e6, T), "t": rng.integers(4, 26, T).astype(float)})
+ls = [{"col": "t", "comp": "<=", "val": 4}, {"col": "t", "comp": ">=", "val": -4}, {"col": ["x", "y"], "comp": "<", "val": 3e5}]
+eng = Engine(0)
+ds = DeviceSelector(df, ls, eng)
+ds.select(xl.iloc[:8])
+t0 = time.perf_counter(); off, idx = ds.select(xl); dt = time.perf_counter() - t0
+import ctypes as C
+km, tm = C.c_double(), C.c_double(); eng._lib.gpsat_last_timing(eng._h, C.byref(km), C.byref(tm))
+print(f"device: count+fill kernels {km.value:.1f} ms, with copies {tm.value:.1f} ms")
+print(f"device: T={T} M={M}: {dt*1e3:.1f} ms wall ({T/dt:.0f} tiles/s), mean N/tile {off[-1]/T:.0f}, {T*M/dt/1e9:.1f} G predicate-rows/s")
+hs = LocalSelector(df, ls)
+t0 = time.perf_counter()
+for t in range(64):
+    hs.mask({c: xl.iloc[t][c] for c in xl.columns})
+dh = (time.perf_counter() - t0) / 64
+print(f"host (reference semantics, KD-tree built once): {dh*1e3:.2f} ms/tile -> {1/dh:.0f} tiles/s")
