@@ -266,17 +266,43 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
         __syncthreads();
         if (sh->fail) break;
         const f64x4 Lop = ldl(c.L.LT, lane);
-        for (int i = j + 1 + w; i < NB; i += NW) {
-            f64x4 acc = zero4();
-            for (int k = 0; k < j; ++k) {
-                const f64x4 A = ldg(c.ws, k * NB + j, lane);
-                const f64x4 B = ldg(c.ws, k * NB + i, lane);
-                mma_blk(acc, A, B);
+        // off-diagonal blocks of row j in groups of 4 columns per wave: the panel block U_kj is loaded once per step
+        // for 4 products, operands of step k+1 are in flight while step k multiplies
+        for (int i0 = j + 1 + 4 * w; i0 < NB; i0 += 4 * NW) {
+            f64x4 acc[4];
+            int ib[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) { acc[n] = zero4(); ib[n] = (i0 + n < NB) ? (i0 + n) : -1; }
+            if (j > 0) {
+                f64x4 A = ldg(c.ws, j, lane);
+                f64x4 B[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) B[n] = ldg(c.ws, ib[n] >= 0 ? ib[n] : c.zb, lane);
+                for (int k = 0; k < j; ++k) {
+                    f64x4 nA = A, nB[4];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) nB[n] = B[n];
+                    if (k + 1 < j) {
+                        nA = ldg(c.ws, (k + 1) * NB + j, lane);
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) nB[n] = ldg(c.ws, ib[n] >= 0 ? (k + 1) * NB + ib[n] : c.zb, lane);
+                    }
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) mma_blk(acc[n], A, B[n]);
+                    A = nA;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) B[n] = nB[n];
+                }
             }
-            acc = kblock<D, KN>(c, j, i) - acc;
-            f64x4 Uo = zero4();
-            mma_blk(Uo, Lop, acc);
-            stg(c.ws, j * NB + i, lane, Uo);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if (ib[n] >= 0) {
+                    const f64x4 Wb = kblock<D, KN>(c, j, ib[n]) - acc[n];
+                    f64x4 Uo = zero4();
+                    mma_blk(Uo, Lop, Wb);
+                    stg(c.ws, j * NB + ib[n], lane, Uo);
+                }
+            }
         }
         __syncthreads();
     }
@@ -409,37 +435,65 @@ __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const double* __rest
                                              double* __restrict__ fv, double* __restrict__ yv, const double* theta) {
     const int NB = c.NB, lane = c.lane;
     const int PC = (c.P + BS - 1) / BS;
-    const int v0 = c.vs0 + c.w * NB;
-    for (int pc = c.w; pc < PC; pc += NW) {
-        const int qa = BS * pc + c.g;
-        const bool va = qa < c.P;
-        double xa[D];
+    const int v0 = c.vs0 + c.w * 4 * NB;           // this wave's V scratch: [4 chunks][NB] blocks
+    for (int pc0 = 4 * c.w; pc0 < PC; pc0 += 4 * NW) {
+        double xa[4][D];
+        bool va[4];
 #pragma unroll
-        for (int d = 0; d < D; ++d) xa[d] = va ? Xs[(size_t)qa * D + d] / theta[d] : 0.0;
-        double vs = 0.0, ms = 0.0;
+        for (int n = 0; n < 4; ++n) {
+            const int qa = BS * (pc0 + n) + c.g;
+            va[n] = qa < c.P;
+#pragma unroll
+            for (int d = 0; d < D; ++d) xa[n][d] = va[n] ? Xs[(size_t)qa * D + d] / theta[d] : 0.0;
+        }
+        double vs[4] = {0.0, 0.0, 0.0, 0.0}, ms[4] = {0.0, 0.0, 0.0, 0.0};
         for (int j = 0; j < NB; ++j) {
-            f64x4 acc = zero4();
-            for (int k = 0; k < j; ++k) {
-                const f64x4 A = ldg(c.ws, k * NB + j, lane);
-                const f64x4 B = ldg(c.ws, v0 + k, lane);
-                mma_blk(acc, A, B);
+            f64x4 acc[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n] = zero4();
+            if (j > 0) {
+                f64x4 A = ldg(c.ws, j, lane);
+                f64x4 B[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) B[n] = ldg(c.ws, v0 + n * NB, lane);
+                for (int k = 0; k < j; ++k) {
+                    f64x4 nA = A, nB[4];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) nB[n] = B[n];
+                    if (k + 1 < j) {
+                        nA = ldg(c.ws, (k + 1) * NB + j, lane);
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) nB[n] = ldg(c.ws, v0 + n * NB + k + 1, lane);
+                    }
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) mma_blk(acc[n], A, B[n]);
+                    A = nA;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) B[n] = nB[n];
+                }
             }
             const f64x4 Lop = ldg(c.ws, c.dT0 + j, lane);
-            const f64x4 Wb = ksblock<D, KN>(c, j, xa, va) - acc;
-            f64x4 V = zero4();
-            mma_blk(V, Lop, Wb);
-            stg(c.ws, v0 + j, lane, V);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                vs = fma(V[r], V[r], vs);
-                ms = fma(V[r], lds_d[c.L.z + BS * j + rowof(r, c.q)], ms);
+            for (int n = 0; n < 4; ++n) {
+                const f64x4 Wb = ksblock<D, KN>(c, j, xa[n], va[n]) - acc[n];
+                f64x4 V = zero4();
+                mma_blk(V, Lop, Wb);
+                stg(c.ws, v0 + n * NB + j, lane, V);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    vs[n] = fma(V[r], V[r], vs[n]);
+                    ms[n] = fma(V[r], lds_d[c.L.z + BS * j + rowof(r, c.q)], ms[n]);
+                }
             }
         }
-        vs = qsum(vs);
-        ms = qsum(ms);
-        if (c.q == 0 && va) {
-            const double var = c.sf2 - vs;
-            fm[qa] = ms; fv[qa] = var; yv[qa] = var + c.sn2;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const double vsum = qsum(vs[n]), msum = qsum(ms[n]);
+            const int qa = BS * (pc0 + n) + c.g;
+            if (c.q == 0 && va[n]) {
+                const double var = c.sf2 - vsum;
+                fm[qa] = msum; fv[qa] = var; yv[qa] = var + c.sn2;
+            }
         }
     }
 }
@@ -591,7 +645,7 @@ size_t shared_bytes_f64(int D, int NBmax) {
 }
 
 size_t workspace_doubles_per_wg_f64(int NBmax) {
-    return (size_t)f64k::BLK * ((size_t)NBmax * NBmax + (size_t)NBmax + (size_t)f64k::NW * NBmax + 1);
+    return (size_t)f64k::BLK * ((size_t)NBmax * NBmax + (size_t)NBmax + (size_t)f64k::NW * 4 * NBmax + 1);
 }
 
 hipError_t launch_tiles_f64(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream) {
