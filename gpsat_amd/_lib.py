@@ -22,7 +22,8 @@ MEM_HOST, MEM_DEVICE = 0, 1
 STATUS = {0: "converged", 1: "max_iter", 2: "not_pd", 3: "nan", 4: "skipped", 5: "not_optimised"}
 
 EXPORTS = ["gpsat_version", "gpsat_last_error", "gpsat_device_count", "gpsat_create", "gpsat_device_name",
-           "gpsat_destroy", "gpsat_fit_predict_batch", "gpsat_last_timing", "gpsat_select_batch"]
+           "gpsat_destroy", "gpsat_fit_predict_batch", "gpsat_last_timing", "gpsat_select_batch",
+           "gpsat_smooth_batch", "gpsat_glue_batch"]
 
 
 class GpsatOpts(C.Structure):
@@ -79,6 +80,11 @@ def load():
     lib.gpsat_select_batch.restype = C.c_int
     lib.gpsat_select_batch.argtypes = [C.c_void_p, C.POINTER(GpsatSelectSpec), C.c_int64, C.c_int32, C.c_void_p, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.gpsat_smooth_batch.restype = C.c_int
+    lib.gpsat_smooth_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+    lib.gpsat_glue_batch.restype = C.c_int
+    lib.gpsat_glue_batch.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
     lib.gpsat_last_timing.restype = C.c_int
     lib.gpsat_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     if lib.gpsat_version() != ABI_VERSION:

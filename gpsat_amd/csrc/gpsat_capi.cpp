@@ -355,6 +355,61 @@ int gpsat_select_batch(gpsat_handle* h, const gpsat_select_spec* sp, int64_t M, 
     return GPSAT_OK;
 }
 
+int gpsat_smooth_batch(gpsat_handle* h, int32_t T, const double* x, const double* y, const double* vals, double l_x,
+                       double l_y, double* out) {
+    if (!h || T < 0 || (T > 0 && (!x || !y || !vals || !out))) return fail(GPSAT_EINVAL, "gpsat_smooth_batch: bad argument");
+    if (!(l_x > 0.0) || !(l_y > 0.0)) return fail(GPSAT_EINVAL, "gpsat_smooth_batch: length scales must be positive");
+    if (T == 0) return GPSAT_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    int rc;
+    if ((rc = h->sel_pts.reserve((size_t)4 * T * sizeof(double)))) return rc;
+    double* d = static_cast<double*>(h->sel_pts.p);
+    HIP_TRY(hipMemcpyAsync(d, x, (size_t)T * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d + T, y, (size_t)T * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d + 2 * (size_t)T, vals, (size_t)T * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+    HIP_TRY(gpsat::launch_smooth(T, d, d + T, d + 2 * (size_t)T, l_x, l_y, d + 3 * (size_t)T, h->stream));
+    HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+    HIP_TRY(hipMemcpyAsync(out, d + 3 * (size_t)T, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float km = 0.f;
+    HIP_TRY(hipEventElapsedTime(&km, h->ev[1], h->ev[2]));
+    h->last_kernel_ms = km; h->last_total_ms = km;
+    return GPSAT_OK;
+}
+
+int gpsat_glue_batch(gpsat_handle* h, int64_t R, int32_t G, int32_t ndim, int32_t nvars, const int64_t* seg,
+                     const double* pred, const double* xprt, const double* vals, double sigma,
+                     const double* sigma_rows, double* out) {
+    if (!h || R < 0 || G < 0) return fail(GPSAT_EINVAL, "gpsat_glue_batch: bad sizes");
+    if (ndim < 1 || ndim > 2 || nvars < 1 || nvars > GPSAT_GLUE_MAXVARS) return fail(GPSAT_EINVAL, "gpsat_glue_batch: ndim 1..2, nvars 1..4");
+    if (!sigma_rows && !(sigma > 0.0)) return fail(GPSAT_EINVAL, "gpsat_glue_batch: sigma must be positive");
+    if (G == 0) return GPSAT_OK;
+    if (!seg || !pred || !xprt || !vals || !out) return fail(GPSAT_EINVAL, "gpsat_glue_batch: NULL argument");
+    if (seg[0] != 0 || seg[G] != R) return fail(GPSAT_EINVAL, "gpsat_glue_batch: seg must run from 0 to R");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc;
+    const size_t nd = (size_t)(2 * ndim + nvars + 1) * R + (size_t)nvars * G;
+    if ((rc = h->sel_pts.reserve(std::max<size_t>(nd, 1) * sizeof(double)))) return rc;
+    if ((rc = h->sel_cnt.reserve((size_t)(G + 1) * sizeof(long long)))) return rc;
+    double* d = static_cast<double*>(h->sel_pts.p);
+    double* dp = d; double* dx = d + (size_t)ndim * R; double* dv = dx + (size_t)ndim * R; double* dsig = dv + (size_t)nvars * R; double* dout = dsig + R;
+    HIP_TRY(hipMemcpyAsync(dp, pred, (size_t)ndim * R * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(dx, xprt, (size_t)ndim * R * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(dv, vals, (size_t)nvars * R * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (sigma_rows) HIP_TRY(hipMemcpyAsync(dsig, sigma_rows, (size_t)R * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->sel_cnt.p, seg, (size_t)(G + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+    HIP_TRY(gpsat::launch_glue(G, ndim, nvars, R, static_cast<const long long*>(h->sel_cnt.p), dp, dx, dv, sigma, sigma_rows ? dsig : nullptr, dout, h->stream));
+    HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+    HIP_TRY(hipMemcpyAsync(out, dout, (size_t)nvars * G * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float km = 0.f;
+    HIP_TRY(hipEventElapsedTime(&km, h->ev[1], h->ev[2]));
+    h->last_kernel_ms = km; h->last_total_ms = km;
+    return GPSAT_OK;
+}
+
 #ifdef GPSAT_PROFILE
 // diagnostic build only: per-wave, per-segment cycle counters of the last call ([4 waves][16 slots])
 int gpsat_debug_profile(gpsat_handle* h, unsigned long long* out64) {

@@ -66,5 +66,12 @@ struct SelectArgs {
 
 hipError_t launch_select(const SelectArgs& a, bool fill, hipStream_t stream);
 
+#define GPSAT_GLUE_MAXVARS 4
+// post-processing (gpsat_post.hip); device pointers
+hipError_t launch_smooth(int T, const double* x, const double* y, const double* vals, double lx, double ly, double* out,
+                         hipStream_t stream);
+hipError_t launch_glue(int G, int ndim, int nvars, long long R, const long long* seg, const double* pred, const double* xprt,
+                       const double* vals, double sigma, const double* sigma_rows, double* out, hipStream_t stream);
+
 }  // namespace gpsat
 #endif

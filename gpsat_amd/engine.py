@@ -189,6 +189,42 @@ class Engine:
                 raise GpsatError(f"gpsat_select_batch failed ({rc}): {self._lib.gpsat_last_error().decode()}")
         return off, idx
 
+    def smooth_batch(self, x, y, vals, l_x: float, l_y: float) -> np.ndarray:
+        """Gaussian smoothing of one hyper-parameter field on the GPU (gpsat_smooth_batch; replaces
+        gaussian_2d_weight, GPSat/postprocessing.py:22-52, with x0, y0 = x, y as smooth_hyperparameters calls it)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        assert x.shape == y.shape == vals.shape and x.ndim == 1
+        out = np.empty_like(vals)
+        rc = self._lib.gpsat_smooth_batch(self._h, len(x), _ptr(x), _ptr(y), _ptr(vals), float(l_x), float(l_y), _ptr(out))
+        if rc != 0:
+            raise GpsatError(f"gpsat_smooth_batch failed ({rc}): {self._lib.gpsat_last_error().decode()}")
+        return out
+
+    def glue_batch(self, seg, pred, xprt, vals, sigma) -> np.ndarray:
+        """Weighted combination of overlapping predictions (gpsat_glue_batch): rows already sorted into segments
+        seg [G+1]; pred, xprt [ndim, R]; vals [nvars, R]; sigma scalar or per row [R]; returns [nvars, G]."""
+        seg = np.ascontiguousarray(seg, dtype=np.int64)
+        pred = np.ascontiguousarray(pred, dtype=np.float64)
+        xprt = np.ascontiguousarray(xprt, dtype=np.float64)
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        ndim, R = pred.shape
+        nvars = vals.shape[0]
+        assert xprt.shape == pred.shape and vals.shape[1] == R
+        G = len(seg) - 1
+        out = np.empty((nvars, G), dtype=np.float64)
+        srow = None
+        if np.ndim(sigma) > 0:
+            srow = np.ascontiguousarray(sigma, dtype=np.float64)
+            assert srow.shape == (R,)
+        rc = self._lib.gpsat_glue_batch(self._h, R, G, ndim, nvars, _ptr(seg), _ptr(pred), _ptr(xprt), _ptr(vals),
+                                        0.0 if srow is not None else float(sigma), _ptr(srow) if srow is not None else None,
+                                        _ptr(out))
+        if rc != 0:
+            raise GpsatError(f"gpsat_glue_batch failed ({rc}): {self._lib.gpsat_last_error().decode()}")
+        return out
+
 
 _default_engine = None
 

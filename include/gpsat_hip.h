@@ -182,6 +182,26 @@ int gpsat_select_batch(gpsat_handle *h, const gpsat_select_spec *spec, int64_t M
                        int32_t T, const double *refs, int64_t *off, int32_t *idx, int64_t capacity);
 
 /*
+ * Gaussian smoothing of one hyper-parameter field over T expert locations (one "other dimensions" slice).
+ * Replaces gaussian_2d_weight (GPSat/postprocessing.py:22-52) as called by smooth_hyperparameters (:277-288, after
+ * the min/max clipping done by the caller).  x, y, vals, out: host fp64 [T]; NaN vals are skipped; out is NaN when
+ * all weights vanish.
+ */
+int gpsat_smooth_batch(gpsat_handle *h, int32_t T, const double *x, const double *y, const double *vals, double l_x,
+                       double l_y, double *out);
+
+/*
+ * Gluing of overlapping local predictions (GPSat/postprocessing.py:447-577): R prediction rows pre-sorted by
+ * prediction location into G segments seg[G+1]; pred, xprt: host fp64 [ndim][R] (ndim 1 or 2); vals: host fp64
+ * [nvars][R] (nvars <= 4); sigma = inference_radius / R_factor, or per row in sigma_rows [R] when not NULL (the
+ * per-expert inference_radius dict of :490-493); out: host fp64 [nvars][G] = sum w v / sum w with
+ * w = prod_d normpdf(pred_d; xprt_d, sigma).
+ */
+int gpsat_glue_batch(gpsat_handle *h, int64_t R, int32_t G, int32_t ndim, int32_t nvars, const int64_t *seg,
+                     const double *pred, const double *xprt, const double *vals, double sigma,
+                     const double *sigma_rows, double *out);
+
+/*
  * Timing of the last gpsat_fit_predict_batch on this handle, measured with HIP events on the
  * handle's stream: kernel_ms = the persistent tile kernel alone, total_ms = H2D + kernel + D2H.
  */

@@ -17,6 +17,8 @@ Sources of truth (none of them travels to the GPU box; only the .npz outputs do)
    docs/notebooks/gp_regression.ipynb (cell 3) together with the values that notebook
    prints (LML 16.6180 -> 21.4700, lengthscale 1.5648, kernel_variance 0.5168).
 4. ``transforms.npz`` -- softplus / sigmoid tables on the grids of tests/test_utils.py:962-1023.
+5. ``ref_post.npz`` -- outputs of the REFERENCE's gaussian_2d_weight and glue_local_predictions_1d/_2d
+   (GPSat/postprocessing.py) on seeded inputs (``python tests/golden/make_golden.py post`` regenerates only this one).
 
 Fixtures are DATA (inputs + expected outputs), never reference source text.
 """
@@ -158,8 +160,93 @@ def transforms():
     print("transform tables written")
 
 
+
+
+def ref_postprocessing():
+    """``ref_post.npz`` -- outputs of the REFERENCE's gaussian_2d_weight body (GPSat/postprocessing.py:28-52; numba
+    is absent, the inert decorator leaves the plain Python function, called once per reference position) and of
+    glue_local_predictions_1d / _2d (:447-577) on seeded inputs."""
+    import pandas as pd
+    import importlib.abc
+    import importlib.machinery
+    roots = {"tensorflow", "tables", "numba", "pyproj", "deprecated", "xarray", "netCDF4", "dataclasses_json", "gpflow",
+             "astropy", "global_land_mask", "matplotlib", "cartopy", "seaborn", "gpytorch", "chardet", "shapely"}
+
+    class _InertFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+        """any module below an absent third-party root resolves to an inert placeholder package"""
+
+        def find_spec(self, fullname, path, target=None):
+            if fullname.split(".")[0] in roots:
+                return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+            return None
+
+        def create_module(self, spec):
+            return _Inert(spec.name)
+
+        def exec_module(self, module):
+            module.__path__ = []
+
+    for k in [k for k in sys.modules if k.split(".")[0] in roots]:
+        del sys.modules[k]
+    sys.meta_path.insert(0, _InertFinder())
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    from GPSat.postprocessing import gaussian_2d_weight, glue_local_predictions_1d, glue_local_predictions_2d
+    rng = np.random.default_rng(77)
+    T = 150
+    x = rng.uniform(-1e6, 1e6, T)
+    y = rng.uniform(-1e6, 1e6, T)
+    vals = np.exp(rng.normal(0, 1, T))
+    vals[rng.choice(T, 17, replace=False)] = np.nan
+    lx, ly = 2.0e5, 3.0e5
+
+    def smooth(x, y, vals, lx, ly):
+        out = np.empty(len(x))
+        o = np.empty(1)
+        for i in range(len(x)):
+            gaussian_2d_weight(x[i], y[i], x, y, np.array([lx]), np.array([ly]), vals, o)
+            out[i] = o[0]
+        return out
+    sm = smooth(x, y, vals, lx, ly)
+    # tiny length scales: isolated NaN points get zero total weight -> NaN out
+    sm_tiny = smooth(x, y, vals, 1.0, 1.0)
+    # gluing, 1-D: 6 experts on a line, prediction grid within the inference radius
+    r1 = 0.15 + 1e-8
+    rows = []
+    grid = np.linspace(0.1, 0.9, 161)
+    for e in np.linspace(0.2, 0.8, 6):
+        g = grid[np.abs(grid - e) < r1]
+        rows.append(pd.DataFrame({"x": e, "pred_loc_x": g, "f*": np.sin(1 / g) + 0.05 * rng.standard_normal(len(g)),
+                                  "f*_var": rng.uniform(1e-4, 1e-2, len(g))}))
+    p1 = pd.concat(rows).sample(frac=1.0, random_state=3).reset_index(drop=True)
+    g1 = glue_local_predictions_1d(p1, "pred_loc_x", "x", ["f*", "f*_var"], r1)
+    # 2-D
+    r2 = 300.0
+    rows = []
+    gx, gy = np.meshgrid(np.arange(-500, 501, 50.0), np.arange(-500, 501, 50.0))
+    gx, gy = gx.ravel(), gy.ravel()
+    for ex in (-250.0, 0.0, 250.0):
+        for ey in (-250.0, 0.0, 250.0):
+            m = (gx - ex) ** 2 + (gy - ey) ** 2 < r2 ** 2
+            n = int(m.sum())
+            rows.append(pd.DataFrame({"x": ex, "y": ey, "pred_loc_x": gx[m], "pred_loc_y": gy[m],
+                                      "f*": rng.standard_normal(n), "f*_var": rng.uniform(0.01, 1, n),
+                                      "y_var": rng.uniform(1, 2, n)}))
+    p2 = pd.concat(rows).sample(frac=1.0, random_state=4).reset_index(drop=True)
+    g2 = glue_local_predictions_2d(p2, ["pred_loc_x", "pred_loc_y"], ["x", "y"], ["f*", "f*_var", "y_var"], r2)
+    np.savez(os.path.join(HERE, "ref_post.npz"), sx=x, sy=y, svals=vals, lx=lx, ly=ly, smoothed=sm, smoothed_tiny=sm_tiny,
+             r1=r1, p1=p1[["x", "pred_loc_x", "f*", "f*_var"]].values, g1=g1[["pred_loc_x", "f*", "f*_var"]].values,
+             r2=r2, p2=p2[["x", "y", "pred_loc_x", "pred_loc_y", "f*", "f*_var", "y_var"]].values,
+             g2=g2[["pred_loc_x", "pred_loc_y", "f*", "f*_var", "y_var"]].values)
+    print("ref post-processing: smoothed NaNs", int(np.isnan(sm).sum()), int(np.isnan(sm_tiny).sum()),
+          "glued rows", len(g1), len(g2))
+
+
 if __name__ == "__main__":
-    kat_sklearn()
-    kat_notebook_rbf()
-    transforms()
-    ref_purepython()
+    if "post" not in sys.argv[1:]:
+        kat_sklearn()
+        kat_notebook_rbf()
+        transforms()
+        ref_purepython()
+    ref_postprocessing()
