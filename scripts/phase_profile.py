@@ -2,7 +2,7 @@
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["GPSAT_LIB"] = os.path.join(ROOT, "gpsat_amd", "csrc", "libgpsat_hip_prof.so")
+os.environ.setdefault("GPSAT_LIB", os.path.join(ROOT, "gpsat_amd", "csrc", "libgpsat_hip_prof.so"))
 import ctypes as C
 import numpy as np, torch
 from gpsat_amd.engine import Engine
@@ -19,7 +19,7 @@ th0 = np.tile(b["truth"], (rep, 1))
 eng = Engine(0, workgroups_per_cu=int(os.environ.get("WG", 2)))
 lib = _lib.get_lib()
 names = ["w0 diag k-loop", "diag_factor", "w0 serial rest", "barrier wait (PT)", "group k-loop", "group rows",
-         "grad c-loop", "grad contraction", "grad final barrier", "evaluate total", "chain flag wait"]
+         "grad c-loop", "grad contraction", "grad final barrier", "evaluate total", "chain flag wait", "park diag partials", "early-start k-loop"]
 for name, kw in [("potrf only", dict(optimiser="none")), ("potrf+trtri+grad", dict(optimiser="none", want_grad=True))]:
     args = dict(D=D, obs_off=obs_off, X=dX, y=dy, pred_off=np.zeros(T + 1, dtype=np.int64), Xs=dXs[:0].contiguous(),
                 theta0=th0, kernel="RBF")
