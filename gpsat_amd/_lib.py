@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPSAT_LIB") or os.path.join(_HERE, "csrc", "libgpsat_hip.so")
 
 # constants mirrored from include/gpsat_hip.h
-ABI_VERSION = 1
+ABI_VERSION = 2
 F32, F64 = 0, 1
 KERNEL_IDS = {"RBF": 0, "SquaredExponential": 0, "Matern12": 1, "Exponential": 1, "Matern32": 2, "Matern52": 3}
 OPT_NONE, OPT_LBFGS, OPT_ADAM = 0, 1, 2
@@ -40,6 +40,7 @@ class GpsatBatch(C.Structure):
         ("X", C.c_void_p), ("y", C.c_void_p), ("Xs", C.c_void_p),
         ("theta", C.c_void_p), ("nll", C.c_void_p), ("grad", C.c_void_p), ("status", C.c_void_p),
         ("n_eval", C.c_void_p), ("f_mean", C.c_void_p), ("f_var", C.c_void_p), ("y_var", C.c_void_p),
+        ("cov_off", C.c_void_p), ("f_cov", C.c_void_p),
     ]
 
 

@@ -151,6 +151,19 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
         maxN = std::max(maxN, n);
     }
     const long long sumN = b->obs_off[T], sumP = b->pred_off[T];
+    // optional full posterior covariance: one P_t x P_t block per tile
+    const bool want_cov = b->f_cov != nullptr;
+    long long sumC = 0, maxP = 0;
+    if (want_cov) {
+        if (!b->cov_off) return fail(GPSAT_EINVAL, "f_cov given without cov_off");
+        if (b->cov_off[0] != 0) return fail(GPSAT_EINVAL, "cov_off must start at 0");
+        for (int t = 0; t < T; ++t) {
+            const long long p = b->pred_off[t + 1] - b->pred_off[t];
+            if (b->cov_off[t + 1] - b->cov_off[t] != p * p) return fail(GPSAT_EINVAL, "cov_off[t+1]-cov_off[t] must equal P_t^2");
+            maxP = std::max(maxP, p);
+        }
+        sumC = b->cov_off[T];
+    }
     if (maxN > (f64 ? 2048 : 4096))
         return fail(GPSAT_EINVAL, "tile too large for this build (4096 observations in fp32, 2048 in fp64)");
     if (sumN > 0 && (!b->X || !b->y)) return fail(GPSAT_EINVAL, "X / y is NULL");
@@ -172,7 +185,8 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     });
 
     // ---- device buffers
-    const size_t n_i64 = 2 * (size_t)(T + 1);
+    const size_t n_i64 = 3 * (size_t)(T + 1);
+    const int PCcov = want_cov ? std::max(1, (int)((maxP + bs - 1) / bs)) : 0;
     const size_t n_f64 = 3 * (size_t)T * H;
     int rc;
     if ((rc = h->meta_i64.reserve(n_i64 * sizeof(long long)))) return rc;
@@ -180,7 +194,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     if ((rc = h->meta_misc.reserve((size_t)T * sizeof(int) + 64 + 16))) return rc;
     if ((rc = h->out_f64.reserve(((size_t)T * H * 2 + (size_t)T) * sizeof(double)))) return rc;
     if ((rc = h->out_i32.reserve((size_t)T * 2 * sizeof(int)))) return rc;
-    const size_t wsf = f64 ? gpsat::workspace_doubles_per_wg_f64(NBmax) : gpsat::workspace_floats_per_wg(NBmax);
+    const size_t wsf = f64 ? gpsat::workspace_doubles_per_wg_f64(NBmax, PCcov) : gpsat::workspace_floats_per_wg(NBmax, PCcov);
     int grid = std::min(T, h->num_cu * h->wg_per_cu);
     const size_t smem = f64 ? gpsat::shared_bytes_f64(D, NBmax) : gpsat::shared_bytes(D, NBmax);
     if (smem > 160 * 1024) return fail(GPSAT_EINVAL, "tile too large for LDS");
@@ -188,12 +202,12 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     if ((rc = h->ws.reserve((size_t)grid * wsf * esz))) return rc;
 
     const char *dX = nullptr, *dy = nullptr, *dXs = nullptr;
-    char *dfm = nullptr, *dfv = nullptr, *dyv = nullptr;
+    char *dfm = nullptr, *dfv = nullptr, *dyv = nullptr, *dcov = nullptr;
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     if (b->memory == GPSAT_MEM_HOST) {
         const size_t in_e = (size_t)sumN * D + (size_t)sumN + (size_t)sumP * D;
         if ((rc = h->bulk_in.reserve(std::max<size_t>(in_e, 1) * esz))) return rc;
-        if ((rc = h->bulk_out.reserve(std::max<size_t>((size_t)sumP * 3, 1) * esz))) return rc;
+        if ((rc = h->bulk_out.reserve(std::max<size_t>((size_t)sumP * 3 + (size_t)sumC, 1) * esz))) return rc;
         char* base = static_cast<char*>(h->bulk_in.p);
         dX = base; dy = base + (size_t)sumN * D * esz; dXs = base + (size_t)sumN * (D + 1) * esz;
         if (sumN > 0) {
@@ -203,13 +217,17 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
         if (sumP > 0)
             HIP_TRY(hipMemcpyAsync(const_cast<char*>(dXs), b->Xs, (size_t)sumP * D * esz, hipMemcpyHostToDevice, h->stream));
         dfm = static_cast<char*>(h->bulk_out.p); dfv = dfm + (size_t)sumP * esz; dyv = dfv + (size_t)sumP * esz;
+        if (want_cov) dcov = dyv + (size_t)sumP * esz;
     } else {
+        dcov = static_cast<char*>(b->f_cov);
         dX = static_cast<const char*>(b->X); dy = static_cast<const char*>(b->y); dXs = static_cast<const char*>(b->Xs);
         dfm = static_cast<char*>(b->f_mean); dfv = static_cast<char*>(b->f_var); dyv = static_cast<char*>(b->y_var);
     }
     long long* d_i64 = static_cast<long long*>(h->meta_i64.p);
     HIP_TRY(hipMemcpyAsync(d_i64, b->obs_off, (size_t)(T + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(d_i64 + (T + 1), b->pred_off, (size_t)(T + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    if (want_cov)
+        HIP_TRY(hipMemcpyAsync(d_i64 + 2 * (T + 1), b->cov_off, (size_t)(T + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
     double* d_f64 = static_cast<double*>(h->meta_f64.p);
     HIP_TRY(hipMemcpyAsync(d_f64, b->theta0, (size_t)T * H * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(d_f64 + (size_t)T * H, b->lo, (size_t)T * H * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -242,6 +260,9 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     a.order = d_order; a.queue = d_queue;
     a.ws = static_cast<float*>(h->ws.p); a.ws_stride = wsf;     // fp64: the kernel reinterprets ws as doubles
     a.prof = nullptr;
+    a.cov_off = want_cov ? d_i64 + 2 * (T + 1) : nullptr;
+    a.f_cov = want_cov ? reinterpret_cast<float*>(dcov) : nullptr;
+    a.PCmax = PCcov;
 #ifdef GPSAT_PROFILE
     if ((rc = h->prof.reserve(64 * sizeof(unsigned long long)))) return rc;
     HIP_TRY(hipMemsetAsync(h->prof.p, 0, 64 * sizeof(unsigned long long), h->stream));
@@ -262,6 +283,8 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
         HIP_TRY(hipMemcpyAsync(b->f_var, dfv, (size_t)sumP * esz, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipMemcpyAsync(b->y_var, dyv, (size_t)sumP * esz, hipMemcpyDeviceToHost, h->stream));
     }
+    if (b->memory == GPSAT_MEM_HOST && want_cov && sumC > 0)
+        HIP_TRY(hipMemcpyAsync(b->f_cov, dcov, (size_t)sumC * esz, hipMemcpyDeviceToHost, h->stream));
 #ifdef GPSAT_PROFILE
     HIP_TRY(hipMemcpyAsync(h->prof_host, h->prof.p, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
 #endif

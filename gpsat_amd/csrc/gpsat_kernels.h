@@ -32,14 +32,17 @@ struct KernelArgs {
     float* ws;                    // per-workgroup workspace
     size_t ws_stride;             // floats per workgroup
     unsigned long long* prof;     // [NW*16] cycle counters (diagnostic build only, else nullptr)
+    const long long* cov_off;     // [T+1] element offsets into f_cov, or nullptr
+    float* f_cov;                 // per tile P x P posterior covariance, or nullptr
+    int PCmax;                    // max prediction chunks per tile (only used with f_cov)
 };
 
 size_t shared_bytes(int D, int NBmax);
 // fp64 kernels (gpsat_kernels_f64.hip): X, y, Xs, f_* and ws of KernelArgs point at doubles, ws_stride counts doubles
 size_t shared_bytes_f64(int D, int NBmax);
-size_t workspace_doubles_per_wg_f64(int NBmax);
+size_t workspace_doubles_per_wg_f64(int NBmax, int PCcov);
 hipError_t launch_tiles_f64(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream);
-size_t workspace_floats_per_wg(int NBmax);
+size_t workspace_floats_per_wg(int NBmax, int PCcov);     // PCcov: prediction chunks kept for f_cov (0 = none)
 hipError_t launch_tiles(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream);
 
 #define GPSAT_SEL_MAXCRIT 4

@@ -170,7 +170,7 @@ template <int D, int KN>
 struct Ctx {
     Lay L;
     float* ws;                   // this workgroup's global workspace
-    int zb, dT0, vs0;            // block indices: zero block, DinvT[0], V scratch
+    int zb, dT0, vs0, cv0;       // block indices: zero block, DinvT[0], V scratch, V of all chunks (full covariance)
     int N, NB, Npad, P;
     int tid, lane, w, h, g;
     float sf2, sn2;
@@ -961,11 +961,14 @@ __device__ __forceinline__ void evaluate(Ctx<D, KN>& c, bool want_grad) {
 // ---------------------------------------------------------------------------------------------
 template <int D, int KN>
 __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const float* __restrict__ Xs, float* __restrict__ fm,
-                                             float* __restrict__ fv, float* __restrict__ yv, const float (&invl)[D]) {
+                                             float* __restrict__ fv, float* __restrict__ yv, const float (&invl)[D],
+                                             float* __restrict__ fcov) {
     const int NB = c.NB, lane = c.lane;
     const int PC = (c.P + 31) / 32;
-    const int v0 = c.vs0 + c.w * 2 * NB;          // this wave's V scratch: [2][NB] blocks
     for (int pc = 2 * c.w; pc < PC; pc += 2 * NW) {
+        // V = L^-1 K_* of the two chunks: this wave's scratch [2][NB] blocks, or (full covariance wanted) the
+        // per-tile store of all chunks
+        const int v0 = fcov ? c.cv0 + pc * NB : c.vs0 + c.w * 2 * NB;
         const int qa = 32 * pc + c.g, qb = qa + 32;
         const bool va = qa < c.P, vb = qb < c.P;
         float xa[D], xb[D];
@@ -1020,6 +1023,51 @@ __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const float* __restr
         if (c.h == 0 && vb) {
             const float var = c.sf2 - vsb;
             fm[qb] = msb; fv[qb] = var; yv[qb] = var + c.sn2;
+        }
+    }
+    if (fcov) {
+        // f*_cov = K_** - V^T V by 32 x 32 blocks (p <= q, mirrored), gpflow_models.py:245-263 (predict_f full_cov)
+        __syncthreads();
+        int idx = 0;
+        for (int p = 0; p < PC; ++p) {
+            for (int q = p; q < PC; ++q, ++idx) {
+                if ((idx & (NW - 1)) != c.w) continue;
+                f32x16 Cb = zero16();
+                f32x16 A = ldg(c.ws, c.cv0 + p * NB, lane), B = ldg(c.ws, c.cv0 + q * NB, lane);
+                for (int k = 0; k < NB; ++k) {
+                    f32x16 nA = A, nB = B;
+                    if (k + 1 < NB) {
+                        nA = ldg(c.ws, c.cv0 + p * NB + k + 1, lane);
+                        nB = ldg(c.ws, c.cv0 + q * NB + k + 1, lane);
+                    }
+                    mma_blk(Cb, A, B);
+                    A = nA; B = nB;
+                }
+                const int qj = 32 * q + c.g;
+                const bool vj = qj < c.P;
+                float xq[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) xq[d] = vj ? Xs[(size_t)qj * D + d] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pi = 32 * p + rho(r, c.h);
+                    if (vj && pi < c.P) {
+                        float r2 = 0.f;
+#pragma unroll
+                        for (int d = 0; d < D; ++d) {
+                            // difference of the raw coordinates, then the scale: (i,j) and (j,i) see exact negations
+                            // whatever the compiler contracts, so the block is bitwise symmetric
+                            const float df = (Xs[(size_t)pi * D + d] - xq[d]) * invl[d];
+                            r2 = fmaf(df, df, r2);
+                        }
+                        float kf, gg;
+                        kfun<KN>(r2, kf, gg);
+                        const float v = c.sf2 * kf - Cb[r];
+                        fcov[(size_t)pi * c.P + qj] = v;
+                        if (p != q) fcov[(size_t)qj * c.P + pi] = v;
+                    }
+                }
+            }
         }
     }
 }
@@ -1078,6 +1126,7 @@ __global__ void __launch_bounds__(NT, 2) gp_tile_kernel(const KernelArgs A) {
         const int NB = c.NB;
         c.dT0 = NB * NB;
         c.vs0 = c.dT0 + NB;
+        c.cv0 = c.vs0 + NW * 2 * NB;
         if (c.N == 0) {
             if (c.tid == 0) {
                 A.status[t] = 4; A.n_eval[t] = 0; A.nll[t] = 0.0;
@@ -1090,6 +1139,24 @@ __global__ void __launch_bounds__(NT, 2) gp_tile_kernel(const KernelArgs A) {
             for (long long q = p0 + c.tid; q < p1; q += NT) {
                 const float sf2 = (float)A.theta0[(size_t)t * H + D], sn2 = (float)A.theta0[(size_t)t * H + D + 1];
                 A.f_mean[q] = 0.f; A.f_var[q] = sf2; A.y_var[q] = sf2 + sn2;
+            }
+            if (A.f_cov) {
+                // prior covariance K_** of an empty tile
+                const int Pn = (int)(p1 - p0);
+                const float sf2 = (float)A.theta0[(size_t)t * H + D];
+                for (long long e = c.tid; e < (long long)Pn * Pn; e += NT) {
+                    const int i = (int)(e / Pn), j = (int)(e % Pn);
+                    float r2 = 0.f;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        const float il = (float)(1.0 / A.theta0[(size_t)t * H + d]);
+                        const float df = (A.Xs[(size_t)(p0 + i) * D + d] - A.Xs[(size_t)(p0 + j) * D + d]) * il;
+                        r2 = fmaf(df, df, r2);
+                    }
+                    float kf, gg;
+                    kfun<KN>(r2, kf, gg);
+                    A.f_cov[A.cov_off[t] + e] = sf2 * kf;
+                }
             }
             continue;
         }
@@ -1148,11 +1215,14 @@ __global__ void __launch_bounds__(NT, 2) gp_tile_kernel(const KernelArgs A) {
                 float invl[D];
 #pragma unroll
                 for (int d = 0; d < D; ++d) invl[d] = (float)(1.0 / sh->theta[d]);
-                predict_tile<D, KN>(c, A.Xs + (size_t)p0 * D, A.f_mean + p0, A.f_var + p0, A.y_var + p0, invl);
+                predict_tile<D, KN>(c, A.Xs + (size_t)p0 * D, A.f_mean + p0, A.f_var + p0, A.y_var + p0, invl,
+                                    A.f_cov ? A.f_cov + A.cov_off[t] : nullptr);
             } else {
                 for (long long q = p0 + c.tid; q < p1; q += NT) {
                     A.f_mean[q] = __builtin_nanf(""); A.f_var[q] = __builtin_nanf(""); A.y_var[q] = __builtin_nanf("");
                 }
+                if (A.f_cov)
+                    for (long long q = A.cov_off[t] + c.tid; q < A.cov_off[t + 1]; q += NT) A.f_cov[q] = __builtin_nanf("");
             }
         }
     }
@@ -1168,9 +1238,11 @@ size_t shared_bytes(int D, int NBmax) {
     return (fl * sizeof(float) + 15) & ~size_t(15);
 }
 
-size_t workspace_floats_per_wg(int NBmax) {
-    // U/M square + DinvT + per-wave V scratch (2 chunks) + one block of zeros
-    return (size_t)BLK * ((size_t)NBmax * NBmax + (size_t)NBmax + (size_t)NW * 2 * NBmax + 1);
+size_t workspace_floats_per_wg(int NBmax, int PCcov) {
+    // U/M square + DinvT + per-wave V scratch (2 chunks) [+ V of all chunks for the full covariance, one spare chunk
+    // for the odd partner] + one block of zeros
+    const size_t cov = PCcov > 0 ? (size_t)(PCcov + 1) * NBmax : 0;
+    return (size_t)BLK * ((size_t)NBmax * NBmax + (size_t)NBmax + (size_t)NW * 2 * NBmax + cov + 1);
 }
 
 template <int D, int KN>

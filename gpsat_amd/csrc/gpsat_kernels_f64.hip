@@ -106,7 +106,7 @@ template <int D, int KN>
 struct Ctx {
     Lay L;
     double* ws;
-    int zb, dT0, vs0;
+    int zb, dT0, vs0, cv0;
     int N, NB, Npad, P;
     int tid, lane, w, q, g;
     double sf2, sn2;
@@ -432,11 +432,13 @@ __device__ __forceinline__ void evaluate(Ctx<D, KN>& c, bool want_grad, const do
 
 template <int D, int KN>
 __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const double* __restrict__ Xs, double* __restrict__ fm,
-                                             double* __restrict__ fv, double* __restrict__ yv, const double* theta) {
+                                             double* __restrict__ fv, double* __restrict__ yv, const double* theta,
+                                             double* __restrict__ fcov) {
     const int NB = c.NB, lane = c.lane;
     const int PC = (c.P + BS - 1) / BS;
-    const int v0 = c.vs0 + c.w * 4 * NB;           // this wave's V scratch: [4 chunks][NB] blocks
     for (int pc0 = 4 * c.w; pc0 < PC; pc0 += 4 * NW) {
+        // this wave's V scratch [4 chunks][NB] blocks, or (full covariance wanted) the per-tile store of all chunks
+        const int v0 = fcov ? c.cv0 + pc0 * NB : c.vs0 + c.w * 4 * NB;
         double xa[4][D];
         bool va[4];
 #pragma unroll
@@ -496,6 +498,49 @@ __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const double* __rest
             }
         }
     }
+    if (fcov) {
+        // f*_cov = K_** - V^T V by 16 x 16 blocks (p <= q, mirrored), gpflow_models.py:245-263 (predict_f full_cov)
+        __syncthreads();
+        int idx = 0;
+        for (int p = 0; p < PC; ++p) {
+            for (int q = p; q < PC; ++q, ++idx) {
+                if ((idx & (NW - 1)) != c.w) continue;
+                f64x4 Cb = zero4();
+                f64x4 A = ldg(c.ws, c.cv0 + p * NB, lane), B = ldg(c.ws, c.cv0 + q * NB, lane);
+                for (int k = 0; k < NB; ++k) {
+                    f64x4 nA = A, nB = B;
+                    if (k + 1 < NB) {
+                        nA = ldg(c.ws, c.cv0 + p * NB + k + 1, lane);
+                        nB = ldg(c.ws, c.cv0 + q * NB + k + 1, lane);
+                    }
+                    mma_blk(Cb, A, B);
+                    A = nA; B = nB;
+                }
+                const int qj = BS * q + c.g;
+                const bool vj = qj < c.P;
+                double xq[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) xq[d] = vj ? Xs[(size_t)qj * D + d] / theta[d] : 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pi = BS * p + rowof(r, c.q);
+                    if (vj && pi < c.P) {
+                        double r2 = 0.0;
+#pragma unroll
+                        for (int d = 0; d < D; ++d) {
+                            const double df = Xs[(size_t)pi * D + d] / theta[d] - xq[d];
+                            r2 = fma(df, df, r2);
+                        }
+                        double kf, gg;
+                        kfun<KN>(r2, kf, gg);
+                        const double v = c.sf2 * kf - Cb[r];
+                        fcov[(size_t)pi * c.P + qj] = v;
+                        if (p != q) fcov[(size_t)qj * c.P + pi] = v;
+                    }
+                }
+            }
+        }
+    }
 }
 
 template <int D, int KN>
@@ -527,6 +572,7 @@ __global__ void __launch_bounds__(NT, 1) gp_tile_kernel_f64(const KernelArgs A) 
     const double* Xs = reinterpret_cast<const double*>(A.Xs);
     double* f_mean = reinterpret_cast<double*>(A.f_mean);
     double* f_var = reinterpret_cast<double*>(A.f_var);
+    double* f_cov = reinterpret_cast<double*>(A.f_cov);
     double* y_var = reinterpret_cast<double*>(A.y_var);
     OptCfg o;
     o.optimiser = A.optimiser; o.max_iter = A.max_iter; o.max_ls = A.max_ls; o.want_grad_out = A.grad != nullptr;
@@ -548,6 +594,7 @@ __global__ void __launch_bounds__(NT, 1) gp_tile_kernel_f64(const KernelArgs A) 
         const int NB = c.NB;
         c.dT0 = NB * NB;
         c.vs0 = c.dT0 + NB;
+        c.cv0 = c.vs0 + NW * 4 * NB;
         if (c.N == 0) {
             if (c.tid == 0) {
                 A.status[t] = 4; A.n_eval[t] = 0; A.nll[t] = 0.0;
@@ -559,6 +606,23 @@ __global__ void __launch_bounds__(NT, 1) gp_tile_kernel_f64(const KernelArgs A) 
             for (long long qq = p0 + c.tid; qq < p1; qq += NT) {
                 const double sf2 = A.theta0[(size_t)t * H + D], sn2 = A.theta0[(size_t)t * H + D + 1];
                 f_mean[qq] = 0.0; f_var[qq] = sf2; y_var[qq] = sf2 + sn2;
+            }
+            if (f_cov) {
+                // prior covariance K_** of an empty tile
+                const int Pn = (int)(p1 - p0);
+                const double sf2 = A.theta0[(size_t)t * H + D];
+                for (long long e = c.tid; e < (long long)Pn * Pn; e += NT) {
+                    const int i = (int)(e / Pn), j = (int)(e % Pn);
+                    double r2 = 0.0;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        const double df = (Xs[(size_t)(p0 + i) * D + d] - Xs[(size_t)(p0 + j) * D + d]) / A.theta0[(size_t)t * H + d];
+                        r2 = fma(df, df, r2);
+                    }
+                    double kf, gg;
+                    kfun<KN>(r2, kf, gg);
+                    f_cov[A.cov_off[t] + e] = sf2 * kf;
+                }
             }
             continue;
         }
@@ -606,11 +670,14 @@ __global__ void __launch_bounds__(NT, 1) gp_tile_kernel_f64(const KernelArgs A) 
         }
         if (c.P > 0) {
             if (!sh->fail) {
-                predict_tile<D, KN>(c, Xs + (size_t)p0 * D, f_mean + p0, f_var + p0, y_var + p0, sh->theta);
+                predict_tile<D, KN>(c, Xs + (size_t)p0 * D, f_mean + p0, f_var + p0, y_var + p0, sh->theta,
+                                    f_cov ? f_cov + A.cov_off[t] : nullptr);
             } else {
                 for (long long qq = p0 + c.tid; qq < p1; qq += NT) {
                     f_mean[qq] = __builtin_nan(""); f_var[qq] = __builtin_nan(""); y_var[qq] = __builtin_nan("");
                 }
+                if (f_cov)
+                    for (long long qq = A.cov_off[t] + c.tid; qq < A.cov_off[t + 1]; qq += NT) f_cov[qq] = __builtin_nan("");
             }
         }
     }
@@ -644,8 +711,10 @@ size_t shared_bytes_f64(int D, int NBmax) {
     return (dbl * sizeof(double) + 15) & ~size_t(15);
 }
 
-size_t workspace_doubles_per_wg_f64(int NBmax) {
-    return (size_t)f64k::BLK * ((size_t)NBmax * NBmax + (size_t)NBmax + (size_t)f64k::NW * 4 * NBmax + 1);
+size_t workspace_doubles_per_wg_f64(int NBmax, int PCcov) {
+    // + V of all prediction chunks when the full covariance is wanted (3 spare chunks: a wave always solves 4 at a time)
+    const size_t cov = PCcov > 0 ? (size_t)(PCcov + 3) * NBmax : 0;
+    return (size_t)f64k::BLK * ((size_t)NBmax * NBmax + (size_t)NBmax + (size_t)f64k::NW * 4 * NBmax + cov + 1);
 }
 
 hipError_t launch_tiles_f64(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream) {

@@ -28,6 +28,8 @@ class BatchResult:
     f_var: object
     y_var: object
     grad: np.ndarray | None = None   # [T, H] dNLL/dtheta at theta (when requested)
+    f_cov: object = None   # full_cov: flat [sum P_t^2] (numpy / torch as f_mean); tile t = f_cov[cov_off[t]:cov_off[t+1]].reshape(P_t, P_t)
+    cov_off: np.ndarray | None = None
     kernel_ms: float = 0.0
     total_ms: float = 0.0
 
@@ -67,13 +69,14 @@ class Engine:
     def fit_predict_batch(self, *, D, obs_off, X, y, pred_off, Xs, theta0, lo=None, hi=None,
                           trainable=None, kernel="Matern32", optimiser="lbfgs", max_iter=10_000,
                           max_ls=0, ftol=0.0, gtol=0.0, adam_lr=0.0, want_grad=False,
-                          out=None, dtype="f32") -> BatchResult:
+                          out=None, dtype="f32", full_cov=False) -> BatchResult:
         """
         X [sumN, D], y [sumN], Xs [sumP, D]: numpy arrays (host mode) or contiguous torch.cuda tensors (device
         mode; outputs are then torch tensors, optionally preallocated via ``out`` = (f_mean, f_var, y_var)).
         ``dtype``: "f32" (default; fp32 MFMA kernels) or "f64" (the reference's native precision, fp64 MFMA
         kernels); host arrays are cast, device tensors must already have that dtype.  Offsets / theta0 / bounds
-        are always host numpy (fp64).
+        are always host numpy (fp64).  ``full_cov``: also return the P_t x P_t posterior covariance of every tile
+        (predict(full_cov=True), gpflow_models.py:245-263).
         """
         obs_off = np.ascontiguousarray(obs_off, dtype=np.int64)
         pred_off = np.ascontiguousarray(pred_off, dtype=np.int64)
@@ -122,6 +125,16 @@ class Engine:
             pX, py, pXs = _ptr(X), _ptr(y), _ptr(Xs)
             pfm, pfv, pyv = _ptr(fm), _ptr(fv), _ptr(yv)
 
+        cov_off = fc = pfc = None
+        if full_cov:
+            Pt = np.diff(pred_off)
+            cov_off = np.concatenate([[0], np.cumsum(Pt * Pt)]).astype(np.int64)
+            if device_mode:
+                fc = torch.empty(max(int(cov_off[-1]), 1), dtype=t_dt, device=X.device)
+                pfc = fc.data_ptr()
+            else:
+                fc = np.empty(max(int(cov_off[-1]), 1), dtype=np_dt)
+                pfc = _ptr(fc)
         theta = np.empty((T, H), dtype=np.float64)
         nll = np.empty(T, dtype=np.float64)
         grad = np.empty((T, H), dtype=np.float64) if want_grad else None
@@ -141,6 +154,7 @@ class Engine:
         b.theta, b.nll, b.grad = _ptr(theta), _ptr(nll), _ptr(grad)
         b.status, b.n_eval = _ptr(status), _ptr(n_eval)
         b.f_mean, b.f_var, b.y_var = pfm, pfv, pyv
+        b.cov_off, b.f_cov = (_ptr(cov_off), pfc) if full_cov else (None, None)
         rc = self._lib.gpsat_fit_predict_batch(self._h, C.byref(b))
         if rc != 0:
             raise GpsatError(f"gpsat_fit_predict_batch failed ({rc}): {self._lib.gpsat_last_error().decode()}")
@@ -149,7 +163,8 @@ class Engine:
         if device_mode:
             fm, fv, yv = fm[:sumP], fv[:sumP], yv[:sumP]
         return BatchResult(theta=theta, nll=nll, status=status, n_eval=n_eval, f_mean=fm, f_var=fv, y_var=yv,
-                           grad=grad, kernel_ms=km.value, total_ms=tm.value)
+                           grad=grad, kernel_ms=km.value, total_ms=tm.value,
+                           f_cov=(fc[:int(cov_off[-1])] if full_cov else None), cov_off=cov_off)
 
 
     def select_batch(self, points: np.ndarray, refs: np.ndarray, criteria):

@@ -324,15 +324,24 @@ class HipGPRModel:
             coords = coords[None, :]
         assert isinstance(coords, np.ndarray), "coords should be an ndarray (one can be converted from)"
         coords = coords.astype(self.coords.dtype)
-        if full_cov:
-            raise NotImplementedError("full_cov=True is not built in the HIP backend")
         if apply_scale:
             coords = coords / self.coords_scale
-        r = self._run(optimiser="none", pred_coords=coords)
+        r = self._run(optimiser="none", pred_coords=coords, full_cov=bool(full_cov))
         if r.status[0] in (2, 3):
             raise FloatingPointError("covariance matrix is not positive definite at the current parameters")
-        out = {"f*": r.f_mean.astype(np.float64), "f*_var": r.f_var.astype(np.float64),
-               "y_var": r.y_var.astype(np.float64)}
+        if not full_cov:
+            out = {"f*": r.f_mean.astype(np.float64), "f*_var": r.f_var.astype(np.float64),
+                   "y_var": r.y_var.astype(np.float64)}
+        else:
+            # gpflow_models.py:245-263: marginal variance = diagonal of the full covariance; the predictive
+            # covariance adds the likelihood variance on the diagonal
+            P = len(coords)
+            f_cov = np.asarray(r.f_cov, dtype=np.float64).reshape(P, P)
+            f_var = np.diag(f_cov).copy()
+            y_var = r.y_var.astype(np.float64)
+            y_cov = f_cov.copy()
+            y_cov[np.arange(P), np.arange(P)] += y_var - f_var
+            out = {"f*": r.f_mean.astype(np.float64), "f*_var": f_var, "y_var": y_var, "f*_cov": f_cov, "y_cov": y_cov}
         f_bar = self.obs_mean[:, 0]
         if len(f_bar) != len(out["f*"]):
             assert len(f_bar) == 1, f"'f_bar' did not match the length of 'f*' and f_bar len is not, got: {len(f_bar)}"

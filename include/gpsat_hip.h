@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GPSAT_ABI_VERSION 1
+#define GPSAT_ABI_VERSION 2
 
 /* error codes */
 #define GPSAT_OK            0
@@ -127,6 +127,11 @@ typedef struct gpsat_batch {
     void    *f_mean;           /* [sum P] host|device (as `memory`): "f*"                    */
     void    *f_var;            /* [sum P] "f*_var"                                           */
     void    *y_var;            /* [sum P] "y_var"                                            */
+
+    /* ---- optional full posterior covariance (predict(full_cov=True), gpflow_models.py:245-263); ABI >= 2 ---- */
+    const int64_t *cov_off;    /* [T+1] host: element offsets into f_cov, cov_off[t+1]-cov_off[t] = P_t^2; NULL = off */
+    void    *f_cov;            /* [sum P_t^2] host|device (as `memory`), element type `dtype`: per tile the      */
+                               /*   row-major P_t x P_t matrix "f*_cov" = K** - K*^T K^-1 K*; NULL = not wanted   */
 } gpsat_batch;
 
 /* library / ABI version (GPSAT_ABI_VERSION) */

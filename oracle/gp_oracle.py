@@ -215,6 +215,22 @@ def predict(kid, X, y, Xs, theta):
     return f, fvar, fvar + sn2
 
 
+def predict_cov(kid, X, y, Xs, theta):
+    """Full posterior covariance f*_cov = K** - V^T V (GPflow predict_f(full_cov=True), as consumed by
+    gpflow_models.py:245-263) and the predictive covariance y_cov = f*_cov + diag(y_var - f*_var)."""
+    X = np.asarray(X, dtype=np.float64)
+    Xs = np.asarray(Xs, dtype=np.float64)
+    N, D = X.shape
+    ell, sf2, sn2 = np.asarray(theta[:D], dtype=np.float64), float(theta[D]), float(theta[D + 1])
+    L = np.linalg.cholesky(kernel_matrix(kid, X, X, ell, sf2) + sn2 * np.eye(N))
+    V = solve_triangular(L, kernel_matrix(kid, X, Xs, ell, sf2), lower=True)
+    f_cov = kernel_matrix(kid, Xs, Xs, ell, sf2) - V.T @ V
+    f_var = np.diag(f_cov)
+    y_cov = f_cov.copy()
+    y_cov[np.arange(len(Xs)), np.arange(len(Xs))] += (f_var + sn2) - f_var
+    return f_cov, y_cov
+
+
 # --------------------------------------------------------------------------
 # the per-tile model: defaults, constraints, optimise, predict
 # --------------------------------------------------------------------------
@@ -347,15 +363,18 @@ class OracleGPR:
         self.opt_result = res
         return bool(res.success)
 
-    def predict(self, coords, apply_scale=True):
+    def predict(self, coords, full_cov=False, apply_scale=True):
         coords = np.asarray(coords, dtype=np.float64)
         if coords.ndim == 1:
             coords = coords[None, :]
         if apply_scale:
             coords = coords / self.coords_scale
         f, fv, yv = predict(self.kid, self.coords, self.obs[:, 0], coords, self.theta)
-        return {"f*": f, "f*_var": fv, "y_var": yv,
-                "f_bar": np.repeat(self.obs_mean[:, 0], len(f))}
+        out = {"f*": f, "f*_var": fv, "y_var": yv, "f_bar": np.repeat(self.obs_mean[:, 0], len(f))}
+        if full_cov:                                                  # gpflow_models.py:245-263
+            out["f*_cov"], out["y_cov"] = predict_cov(self.kid, self.coords, self.obs[:, 0], coords, self.theta)
+            out["f*_var"] = np.diag(out["f*_cov"]).copy()
+        return out
 
 
 # --------------------------------------------------------------------------

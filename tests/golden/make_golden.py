@@ -52,7 +52,11 @@ def kat_sklearn():
     test_index = np.random.randint(0, 99)
     x_test = x[[test_index]]
     pred_mean, pred_std = gp.predict(x_test, return_std=True)
-    np.savez(os.path.join(HERE, "kat_sklearn_matern32.npz"),
+    # full posterior covariance at a few grid points (sklearn return_cov: the reference's sklearnGPRModel full_cov path)
+    cov_index = np.array([5, 40, 41, 42, 77, 93])
+    cov_mean, cov = gp.predict(x[cov_index], return_cov=True)
+    np.savez(os.path.join(HERE, "kat_sklearn_matern32.npz"), cov_index=cov_index, cov_x=x[cov_index, 0], cov=cov,
+             cov_mean=np.ravel(cov_mean),
              x_train=x_train[:, 0], y_train=y_train[:, 0], eps=eps, ls=ls, ml=ml,
              test_index=test_index, x_test=x_test[0, 0],
              pred_mean=np.ravel(pred_mean)[0], pred_std=np.ravel(pred_std)[0])

@@ -32,6 +32,13 @@ def test_kat_sklearn_matern32(golden_dir):
     assert abs(out["f*"][0] - float(g["pred_mean"])) < tol
     assert abs(out["f*_var"][0] - float(g["pred_std"]) ** 2) < tol
     assert abs(out["y_var"][0] - (float(g["pred_std"]) ** 2 + 1e-4)) < tol
+    # full posterior covariance against sklearn's return_cov at the same optimum
+    m.set_parameters(lengthscales=float(g["ls"]))
+    oc = m.predict(g["cov_x"][:, None], full_cov=True)
+    np.testing.assert_allclose(oc["f*_cov"], g["cov"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(oc["f*"], g["cov_mean"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(np.diag(oc["y_cov"]), oc["y_var"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(oc["y_cov"] - oc["f*_cov"], 1e-4 * np.eye(len(g["cov_x"])), rtol=0, atol=1e-15)
 
 
 @pytest.mark.parametrize("N", [16, 128, 500])
