@@ -23,7 +23,12 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 extern __shared__ __attribute__((aligned(16))) double lds_d[];
 
+#ifndef GPSAT_F64_NW
+#define GPSAT_F64_NW 8
+#endif
+#define GPSAT_NW GPSAT_F64_NW     // one workgroup per CU (LDS): 8 waves = 2 per SIMD hide the operand latency
 #include "gpsat_opt.h"
+#undef GPSAT_NW
 
 constexpr int BS = 16;         // block size
 constexpr int BLK = 256;       // doubles per block
@@ -100,7 +105,7 @@ __device__ __forceinline__ void kfun(double r2, double& kf, double& gg) {
     }
 }
 
-struct Lay { int xsc, y, z, alpha, Ad, LT, tmp; };   // double offsets into lds_d
+struct Lay { int xsc, y, z, alpha, Ad, LT, tmp, Pn, tp4; };   // double offsets into lds_d
 
 template <int D, int KN>
 struct Ctx {
@@ -228,79 +233,168 @@ __device__ __forceinline__ void diag_factor(const f64x4& W, int Ad, int lane, f6
     bad = isbad;
 }
 
-// ---- phase 1: K = U^T U by block rows, z = L^-1 y
+// ---- phase 1: K = U^T U by panels of PR = 4 block rows, z = L^-1 y.
+// HBM traffic sets the pace at N ~ 2000 (the 32 MB factor of a tile lives in HBM): with one block row per step every
+// operand block U_ki was loaded once per PRODUCT (3.2 flop/B, measured 3.3 TB/s = HBM-bound at 22 % of the MFMA peak);
+// with 4-row panels a wave keeps 4 x 2 accumulators and loads U_ki once per 4 products (the 4 panel blocks U_k,jr are
+// common to all waves: L1/L2 hits).  Per panel: (A) the 10 diagonal-region sums K - sum_k U_k,jr^T U_k,jr' spread over
+// the waves -> LDS; (B) wave 0 factorises the 4 x 4 block triangle (4 16x16 factorisations, 6 U_rr', forward solve);
+// (C) every wave: column pairs right of the panel, k-loop then the in-panel triangular solve in registers.
+constexpr int PR = 4;
+__device__ __forceinline__ constexpr int pidx(int r, int r2) { return r * PR - (r * (r - 1)) / 2 + (r2 - r); }   // r <= r2 < 4
+
 template <int D, int KN>
 __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
     Shared* sh = reinterpret_cast<Shared*>(lds_d);
     const int NB = c.NB, lane = c.lane, w = c.w;
     if (c.tid == 0) { sh->logdet = 0.0; sh->fail = 0; }
     __syncthreads();
-    for (int j = 0; j < NB; ++j) {
-        if (w == 0) {
-            f64x4 Dd = zero4();
+    for (int j0 = 0; j0 < NB; j0 += PR) {
+        const int nr = min(PR, NB - j0);
+        // ---- (A) diagonal region: D_rr' = K_jr,jr' - sum_{k<j0} U_k,jr^T U_k,jr'  and  t_r = sum_{k<j0} U_k,jr^T z_k
+        for (int bb = w; bb < 10; bb += NW) {
+            int r = 0, r2 = bb;
+            if (bb >= 9) { r = 3; r2 = 3; } else if (bb >= 7) { r = 2; r2 = bb - 5; } else if (bb >= 4) { r = 1; r2 = bb - 3; }
+            if (r2 >= nr) continue;
+            const bool dg = (r == r2);
+            f64x4 acc = zero4();
             double tp = 0.0;
-            for (int k = 0; k < j; ++k) {
-                const f64x4 A = ldg(c.ws, k * NB + j, lane);
-                mma_blk(Dd, A, A);
+            if (j0 > 0) {
+                f64x4 A = ldg(c.ws, j0 + r, lane), B = ldg(c.ws, j0 + r2, lane);
+                for (int k = 0; k < j0; ++k) {
+                    f64x4 nA = A, nB = B;
+                    if (k + 1 < j0) {
+                        nA = ldg(c.ws, (k + 1) * NB + j0 + r, lane);
+                        nB = ldg(c.ws, (k + 1) * NB + j0 + r2, lane);
+                    }
+                    mma_blk(acc, A, B);
+                    if (dg) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) tp = fma(A[r], lds_d[c.L.z + BS * k + rowof(r, c.q)], tp);
+                        for (int rr = 0; rr < 4; ++rr) tp = fma(A[rr], lds_d[c.L.z + BS * k + rowof(rr, c.q)], tp);
+                    }
+                    A = nA; B = nB;
+                }
             }
-            Dd = kblock<D, KN>(c, j, j) - Dd;
-            f64x4 S1, S2;
-            double ls;
-            int bad;
-            diag_factor(Dd, c.L.Ad, lane, S1, S2, ls, bad);
-            stg(c.ws, j * NB + j, lane, S1);
-            stg(c.ws, c.dT0 + j, lane, S2);
-            stl(c.L.LT, lane, S2);
-            const double t = qsum(tp);
-            if (c.q == 0) lds_d[c.L.tmp + c.g] = lds_d[c.L.y + BS * j + c.g] - t;
-            wave_lds_sync();
-            double zz = 0.0;
+            acc = kblock<D, KN>(c, j0 + r, j0 + r2) - acc;
+            stl(c.L.Pn + bb * BLK, lane, acc);
+            if (dg) {
+                const double t = qsum(tp);
+                if (c.q == 0) lds_d[c.L.tp4 + BS * r + c.g] = t;
+            }
+        }
+        __syncthreads();
+        // ---- (B) the 4 x 4 block triangle (wave 0): after it slot (r,r) of Pn holds (L_r^-1)^T, slot (r,r') holds U_jr,jr'
+        if (w == 0) {
+            f64x4 Dd[10];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) zz = fma(S2[r], lds_d[c.L.tmp + rowof(r, c.q)], zz);
-            zz = qsum(zz);
-            if (c.q == 0) lds_d[c.L.z + BS * j + c.g] = zz;
-            if (lane == 0) { sh->logdet += ls; if (bad) sh->fail = 1; }
+            for (int bb = 0; bb < 10; ++bb) Dd[bb] = ldl(c.L.Pn + bb * BLK, lane);
+            double tpx[PR] = {0.0, 0.0, 0.0, 0.0};      // per-lane partials of t_r' from the rows of this panel
+#pragma unroll
+            for (int r = 0; r < PR; ++r) {
+                if (r < nr) {
+                    const int jr = j0 + r;
+                    f64x4 S1, S2;
+                    double ls;
+                    int bad;
+                    diag_factor(Dd[pidx(r, r)], c.L.Ad, lane, S1, S2, ls, bad);
+                    stg(c.ws, jr * NB + jr, lane, S1);
+                    stg(c.ws, c.dT0 + jr, lane, S2);
+                    stl(c.L.Pn + pidx(r, r) * BLK, lane, S2);
+                    const double t = lds_d[c.L.tp4 + BS * r + c.g] + qsum(tpx[r]);
+                    if (c.q == 0) lds_d[c.L.tmp + c.g] = lds_d[c.L.y + BS * jr + c.g] - t;
+                    wave_lds_sync();
+                    double zz = 0.0;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) zz = fma(S2[rr], lds_d[c.L.tmp + rowof(rr, c.q)], zz);
+                    zz = qsum(zz);
+                    if (c.q == 0) lds_d[c.L.z + BS * jr + c.g] = zz;
+                    if (lane == 0) { sh->logdet += ls; if (bad) sh->fail = 1; }
+                    wave_lds_sync();
+#pragma unroll
+                    for (int r2 = r + 1; r2 < PR; ++r2) {
+                        if (r2 < nr) {
+                            f64x4 U = zero4();
+                            mma_blk(U, S2, Dd[pidx(r, r2)]);
+                            Dd[pidx(r, r2)] = U;
+                            stg(c.ws, jr * NB + j0 + r2, lane, U);
+                            stl(c.L.Pn + pidx(r, r2) * BLK, lane, U);
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) tpx[r2] = fma(U[rr], lds_d[c.L.z + BS * jr + rowof(rr, c.q)], tpx[r2]);
+                        }
+                    }
+#pragma unroll
+                    for (int r2 = r + 1; r2 < PR; ++r2) {
+#pragma unroll
+                        for (int r3 = r2; r3 < PR; ++r3) {
+                            if (r3 < nr) {
+                                f64x4 T = zero4();
+                                mma_blk(T, Dd[pidx(r, r2)], Dd[pidx(r, r3)]);
+                                Dd[pidx(r2, r3)] -= T;
+                            }
+                        }
+                    }
+                }
+            }
         }
         __syncthreads();
         if (sh->fail) break;
-        const f64x4 Lop = ldl(c.L.LT, lane);
-        // off-diagonal blocks of row j in groups of 4 columns per wave: the panel block U_kj is loaded once per step
-        // for 4 products, operands of step k+1 are in flight while step k multiplies
-        for (int i0 = j + 1 + 4 * w; i0 < NB; i0 += 4 * NW) {
-            f64x4 acc[4];
-            int ib[4];
+        // ---- (C) columns right of the panel, two per wave and step: 4 x 2 accumulators, operands of step k+1 in flight
+        for (int i0 = j0 + nr + 2 * w; i0 < NB; i0 += 2 * NW) {
+            const int ib0 = i0, ib1 = (i0 + 1 < NB) ? i0 + 1 : -1;
+            f64x4 acc[PR][2];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) { acc[n] = zero4(); ib[n] = (i0 + n < NB) ? (i0 + n) : -1; }
-            if (j > 0) {
-                f64x4 A = ldg(c.ws, j, lane);
-                f64x4 B[4];
+            for (int r = 0; r < PR; ++r) { acc[r][0] = zero4(); acc[r][1] = zero4(); }
+            if (j0 > 0) {
+                f64x4 A[PR], B0, B1;
 #pragma unroll
-                for (int n = 0; n < 4; ++n) B[n] = ldg(c.ws, ib[n] >= 0 ? ib[n] : c.zb, lane);
-                for (int k = 0; k < j; ++k) {
-                    f64x4 nA = A, nB[4];
+                for (int r = 0; r < PR; ++r) A[r] = ldg(c.ws, (r < nr) ? j0 + r : c.zb, lane);
+                B0 = ldg(c.ws, ib0, lane);
+                B1 = ldg(c.ws, ib1 >= 0 ? ib1 : c.zb, lane);
+                for (int k = 0; k < j0; ++k) {
+                    f64x4 nA[PR], nB0 = B0, nB1 = B1;
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) nB[n] = B[n];
-                    if (k + 1 < j) {
-                        nA = ldg(c.ws, (k + 1) * NB + j, lane);
+                    for (int r = 0; r < PR; ++r) nA[r] = A[r];
+                    if (k + 1 < j0) {
 #pragma unroll
-                        for (int n = 0; n < 4; ++n) nB[n] = ldg(c.ws, ib[n] >= 0 ? (k + 1) * NB + ib[n] : c.zb, lane);
+                        for (int r = 0; r < PR; ++r) nA[r] = ldg(c.ws, (r < nr) ? (k + 1) * NB + j0 + r : c.zb, lane);
+                        nB0 = ldg(c.ws, (k + 1) * NB + ib0, lane);
+                        nB1 = ldg(c.ws, ib1 >= 0 ? (k + 1) * NB + ib1 : c.zb, lane);
                     }
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) mma_blk(acc[n], A, B[n]);
-                    A = nA;
+                    for (int r = 0; r < PR; ++r) { mma_blk(acc[r][0], A[r], B0); mma_blk(acc[r][1], A[r], B1); }
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) B[n] = nB[n];
+                    for (int r = 0; r < PR; ++r) A[r] = nA[r];
+                    B0 = nB0; B1 = nB1;
+                }
+            }
+            // right-hand sides, then the in-panel triangular solve: X_r = L_r^-1 (W_r - sum_{r''<r} U_r''r^T X_r'')
+#pragma unroll
+            for (int r = 0; r < PR; ++r) {
+                if (r < nr) {
+                    acc[r][0] = kblock<D, KN>(c, j0 + r, ib0) - acc[r][0];
+                    if (ib1 >= 0) acc[r][1] = kblock<D, KN>(c, j0 + r, ib1) - acc[r][1];
                 }
             }
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                if (ib[n] >= 0) {
-                    const f64x4 Wb = kblock<D, KN>(c, j, ib[n]) - acc[n];
-                    f64x4 Uo = zero4();
-                    mma_blk(Uo, Lop, Wb);
-                    stg(c.ws, j * NB + ib[n], lane, Uo);
+            for (int r = 0; r < PR; ++r) {
+                if (r < nr) {
+                    const f64x4 Lop = ldl(c.L.Pn + pidx(r, r) * BLK, lane);
+                    f64x4 X0 = zero4(), X1 = zero4();
+                    mma_blk(X0, Lop, acc[r][0]);
+                    mma_blk(X1, Lop, acc[r][1]);
+                    stg(c.ws, (j0 + r) * NB + ib0, lane, X0);
+                    if (ib1 >= 0) stg(c.ws, (j0 + r) * NB + ib1, lane, X1);
+#pragma unroll
+                    for (int r2 = r + 1; r2 < PR; ++r2) {
+                        if (r2 < nr) {
+                            const f64x4 U = ldl(c.L.Pn + pidx(r, r2) * BLK, lane);
+                            f64x4 T0 = zero4(), T1 = zero4();
+                            mma_blk(T0, U, X0);
+                            mma_blk(T1, U, X1);
+                            acc[r2][0] -= T0;
+                            acc[r2][1] -= T1;
+                        }
+                    }
                 }
             }
         }
@@ -436,60 +530,80 @@ __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const double* __rest
                                              double* __restrict__ fcov) {
     const int NB = c.NB, lane = c.lane;
     const int PC = (c.P + BS - 1) / BS;
-    for (int pc0 = 4 * c.w; pc0 < PC; pc0 += 4 * NW) {
-        // this wave's V scratch [4 chunks][NB] blocks, or (full covariance wanted) the per-tile store of all chunks
+    // V = L^-1 K_* for two 16-column chunks per wave, by panels of PR block rows like phase_potrf: 4 x 2 accumulators,
+    // every V block (wave-private scratch) is loaded once per 4 products and the factor once per pair of chunks
+    for (int pc0 = 2 * c.w; pc0 < PC; pc0 += 2 * NW) {
+        // this wave's V scratch [2 chunks][NB] blocks, or (full covariance wanted) the per-tile store of all chunks
         const int v0 = fcov ? c.cv0 + pc0 * NB : c.vs0 + c.w * 4 * NB;
-        double xa[4][D];
-        bool va[4];
+        double xa[2][D];
+        bool va[2];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < 2; ++n) {
             const int qa = BS * (pc0 + n) + c.g;
             va[n] = qa < c.P;
 #pragma unroll
             for (int d = 0; d < D; ++d) xa[n][d] = va[n] ? Xs[(size_t)qa * D + d] / theta[d] : 0.0;
         }
-        double vs[4] = {0.0, 0.0, 0.0, 0.0}, ms[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int j = 0; j < NB; ++j) {
-            f64x4 acc[4];
+        double vs[2] = {0.0, 0.0}, ms[2] = {0.0, 0.0};
+        for (int j0 = 0; j0 < NB; j0 += PR) {
+            const int nr = min(PR, NB - j0);
+            f64x4 acc[PR][2];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[n] = zero4();
-            if (j > 0) {
-                f64x4 A = ldg(c.ws, j, lane);
-                f64x4 B[4];
+            for (int r = 0; r < PR; ++r) { acc[r][0] = zero4(); acc[r][1] = zero4(); }
+            if (j0 > 0) {
+                f64x4 A[PR], B0, B1;
 #pragma unroll
-                for (int n = 0; n < 4; ++n) B[n] = ldg(c.ws, v0 + n * NB, lane);
-                for (int k = 0; k < j; ++k) {
-                    f64x4 nA = A, nB[4];
+                for (int r = 0; r < PR; ++r) A[r] = ldg(c.ws, (r < nr) ? j0 + r : c.zb, lane);
+                B0 = ldg(c.ws, v0, lane);
+                B1 = ldg(c.ws, v0 + NB, lane);
+                for (int k = 0; k < j0; ++k) {
+                    f64x4 nA[PR], nB0 = B0, nB1 = B1;
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) nB[n] = B[n];
-                    if (k + 1 < j) {
-                        nA = ldg(c.ws, (k + 1) * NB + j, lane);
+                    for (int r = 0; r < PR; ++r) nA[r] = A[r];
+                    if (k + 1 < j0) {
 #pragma unroll
-                        for (int n = 0; n < 4; ++n) nB[n] = ldg(c.ws, v0 + n * NB + k + 1, lane);
+                        for (int r = 0; r < PR; ++r) nA[r] = ldg(c.ws, (r < nr) ? (k + 1) * NB + j0 + r : c.zb, lane);
+                        nB0 = ldg(c.ws, v0 + k + 1, lane);
+                        nB1 = ldg(c.ws, v0 + NB + k + 1, lane);
                     }
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) mma_blk(acc[n], A, B[n]);
-                    A = nA;
+                    for (int r = 0; r < PR; ++r) { mma_blk(acc[r][0], A[r], B0); mma_blk(acc[r][1], A[r], B1); }
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) B[n] = nB[n];
+                    for (int r = 0; r < PR; ++r) A[r] = nA[r];
+                    B0 = nB0; B1 = nB1;
                 }
             }
-            const f64x4 Lop = ldg(c.ws, c.dT0 + j, lane);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const f64x4 Wb = ksblock<D, KN>(c, j, xa[n], va[n]) - acc[n];
-                f64x4 V = zero4();
-                mma_blk(V, Lop, Wb);
-                stg(c.ws, v0 + n * NB + j, lane, V);
+            for (int r = 0; r < PR; ++r) {
+                if (r < nr) {
+                    const int jr = j0 + r;
+                    const f64x4 Lop = ldg(c.ws, c.dT0 + jr, lane);
+                    f64x4 V[2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    vs[n] = fma(V[r], V[r], vs[n]);
-                    ms[n] = fma(V[r], lds_d[c.L.z + BS * j + rowof(r, c.q)], ms[n]);
+                    for (int n = 0; n < 2; ++n) {
+                        const f64x4 Wb = ksblock<D, KN>(c, jr, xa[n], va[n]) - acc[r][n];
+                        V[n] = zero4();
+                        mma_blk(V[n], Lop, Wb);
+                        stg(c.ws, v0 + n * NB + jr, lane, V[n]);
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            vs[n] = fma(V[n][rr], V[n][rr], vs[n]);
+                            ms[n] = fma(V[n][rr], lds_d[c.L.z + BS * jr + rowof(rr, c.q)], ms[n]);
+                        }
+                    }
+#pragma unroll
+                    for (int r2 = r + 1; r2 < PR; ++r2) {
+                        if (r2 < nr) {
+                            const f64x4 U = ldg(c.ws, jr * NB + j0 + r2, lane);
+                            mma_blk(acc[r2][0], U, V[0]);
+                            mma_blk(acc[r2][1], U, V[1]);
+                        }
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < 2; ++n) {
             const double vsum = qsum(vs[n]), msum = qsum(ms[n]);
             const int qa = BS * (pc0 + n) + c.g;
             if (c.q == 0 && va[n]) {
@@ -562,6 +676,8 @@ __global__ void __launch_bounds__(NT, 1) gp_tile_kernel_f64(const KernelArgs A) 
     c.L.LT = off; off += BLK;
     c.L.Ad = off; off += 16 * 17;
     c.L.tmp = off; off += 16;
+    c.L.Pn = off; off += 10 * BLK;         // diagonal region of the current panel (phase_potrf)
+    c.L.tp4 = off; off += 4 * BS;
     double* wsall = reinterpret_cast<double*>(A.ws);
     const size_t stride = A.ws_stride;                 // doubles per workgroup
     c.ws = wsall + (size_t)blockIdx.x * stride;
@@ -707,12 +823,12 @@ static hipError_t launch_d(const KernelArgs& a, int grid, size_t smem, hipStream
 
 size_t shared_bytes_f64(int D, int NBmax) {
     const size_t NP = (size_t)NBmax * f64k::BS;
-    const size_t dbl = (sizeof(f64k::Shared) + 15) / 16 * 2 + D * NP + 3 * NP + f64k::BLK + 16 * 17 + 16 + 2;
+    const size_t dbl = (sizeof(f64k::Shared) + 15) / 16 * 2 + D * NP + 3 * NP + f64k::BLK + 16 * 17 + 16 + 10 * f64k::BLK + 4 * f64k::BS + 2;
     return (dbl * sizeof(double) + 15) & ~size_t(15);
 }
 
 size_t workspace_doubles_per_wg_f64(int NBmax, int PCcov) {
-    // + V of all prediction chunks when the full covariance is wanted (3 spare chunks: a wave always solves 4 at a time)
+    // + V of all prediction chunks when the full covariance is wanted (spare chunks: a wave always solves 2 at a time)
     const size_t cov = PCcov > 0 ? (size_t)(PCcov + 3) * NBmax : 0;
     return (size_t)f64k::BLK * ((size_t)NBmax * NBmax + (size_t)NBmax + (size_t)f64k::NW * 4 * NBmax + cov + 1);
 }

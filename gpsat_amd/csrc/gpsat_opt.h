@@ -3,8 +3,11 @@
 #ifndef GPSAT_OPT_H
 #define GPSAT_OPT_H
 
-constexpr int NW = 4;          // waves per workgroup
-constexpr int NT = 256;        // threads per workgroup
+#ifndef GPSAT_NW
+#define GPSAT_NW 4
+#endif
+constexpr int NW = GPSAT_NW;   // waves per workgroup (power of two; fp32 kernels 4, fp64 kernels see gpsat_kernels_f64.hip)
+constexpr int NT = 64 * NW;    // threads per workgroup
 constexpr int HMAX = 6;        // max D + 2 (D <= 4)
 constexpr int MH = 8;          // L-BFGS history
 
