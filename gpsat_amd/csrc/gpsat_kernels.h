@@ -44,6 +44,10 @@ size_t workspace_doubles_per_wg_f64(int NBmax, int PCcov);
 hipError_t launch_tiles_f64(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream);
 size_t workspace_floats_per_wg(int NBmax, int PCcov);     // PCcov: prediction chunks kept for f_cov (0 = none)
 hipError_t launch_tiles(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream);
+// 8-wave build of the same kernels (gpsat_kernels.hip -DGPSAT_W8): used when a workgroup needs more than half of the LDS
+size_t shared_bytes_w8(int D, int NBmax);
+size_t workspace_floats_per_wg_w8(int NBmax, int PCcov);
+hipError_t launch_tiles_w8(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream);
 
 #define GPSAT_SEL_MAXCRIT 4
 

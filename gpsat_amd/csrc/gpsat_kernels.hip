@@ -44,7 +44,22 @@
 #define PROF_END(c_, slot_) do {} while (0)
 #endif
 
+// Two builds of this file are linked: the default (4 waves per workgroup, two workgroups per CU when the tile's LDS
+// allows) and -DGPSAT_W8 (8 waves, for batches whose largest tile needs more than half of the LDS, so that a CU still
+// runs two waves per SIMD).  The variant lives in its own inner namespace; the entry points carry a suffix.
+#ifdef GPSAT_W8
+#define GPSAT_NW 8
+#define GPSAT_VNS w8
+#define GPSAT_VFN(name) name##_w8
+#define GPSAT_MIN_WG 1
+#else
+#define GPSAT_VNS w4
+#define GPSAT_VFN(name) name
+#define GPSAT_MIN_WG 2
+#endif
+
 namespace gpsat {
+namespace GPSAT_VNS {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1076,7 +1091,7 @@ __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const float* __restr
 // the persistent kernel
 // ---------------------------------------------------------------------------------------------
 template <int D, int KN>
-__global__ void __launch_bounds__(NT, 2) gp_tile_kernel(const KernelArgs A) {
+__global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelArgs A) {
     constexpr int H = D + 2;
     Ctx<D, KN> c;
     c.tid = threadIdx.x;
@@ -1274,6 +1289,14 @@ hipError_t launch_tiles(int D, const KernelArgs& a, int grid, size_t smem, hipSt
         case 3: return launch_d<3>(a, grid, smem, stream);
         default: return hipErrorInvalidValue;
     }
+}
+
+}  // namespace GPSAT_VNS
+
+size_t GPSAT_VFN(shared_bytes)(int D, int NBmax) { return GPSAT_VNS::shared_bytes(D, NBmax); }
+size_t GPSAT_VFN(workspace_floats_per_wg)(int NBmax, int PCcov) { return GPSAT_VNS::workspace_floats_per_wg(NBmax, PCcov); }
+hipError_t GPSAT_VFN(launch_tiles)(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream) {
+    return GPSAT_VNS::launch_tiles(D, a, grid, smem, stream);
 }
 
 }  // namespace gpsat
