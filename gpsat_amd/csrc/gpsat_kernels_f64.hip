@@ -403,40 +403,112 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
     __syncthreads();
 }
 
-// ---- phase 2: M = L^-1 by block columns (one wave per column), alpha = M^T z
+// ---- phase 2: M = L^-1 (lower slots), alpha = M^T z, by panels of PR block rows (same blocking as phase_potrf:
+// a wave owns pairs of block columns, 4 x 2 accumulators, every streamed block is loaded once per 4 products):
+//   M_ij = -L_i^-1 sum_{k=j}^{i-1} U_ki^T M_kj   (M_jj = L_j^-1 already in the diagonal slot)
 template <int D, int KN>
 __device__ __forceinline__ void phase_trtri(Ctx<D, KN>& c) {
-    const int NB = c.NB, lane = c.lane;
-    for (int j0 = 0; j0 < NB; j0 += NW) {
-        const int rnd = j0 / NW;
-        const int j = j0 + ((rnd & 1) ? (NW - 1 - c.w) : c.w);
-        if (j >= NB) continue;
-        const f64x4 Mjj = ldg(c.ws, j * NB + j, lane);
-        double ap = 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ap = fma(Mjj[r], lds_d[c.L.z + BS * j + rowof(r, c.q)], ap);
-        for (int i = j + 1; i < NB; ++i) {
-            f64x4 acc = zero4();
-            for (int k = j; k < i; ++k) {
-                const f64x4 A = ldg(c.ws, k * NB + i, lane);        // U_ki
-                const f64x4 B = ldg(c.ws, k * NB + j, lane);        // M_kj (k == j: diagonal slot)
-                mma_blk(acc, A, B);
-            }
-            const f64x4 Lop = ldg(c.ws, c.dT0 + i, lane);
-            f64x4 Mij = zero4();
-            mma_blk(Mij, Lop, acc);
-            Mij = -Mij;
-            stg(c.ws, i * NB + j, lane, Mij);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ap = fma(Mij[r], lds_d[c.L.z + BS * i + rowof(r, c.q)], ap);
-        }
-        const double a = qsum(ap);
-        if (c.q == 0) lds_d[c.L.alpha + BS * j + c.g] = a;
-    }
+    const int NB = c.NB, lane = c.lane, w = c.w;
+    for (int idx = c.tid; idx < c.Npad; idx += NT) lds_d[c.L.alpha + idx] = 0.0;
     __syncthreads();
+    for (int i0 = 0; i0 < NB; i0 += PR) {
+        const int nr = min(PR, NB - i0);
+        // (1) column pairs left of the panel
+        for (int p = w; 2 * p < i0; p += NW) {
+            const int jc0 = 2 * p, jc1 = jc0 + 1;
+            f64x4 acc[PR][2];
+#pragma unroll
+            for (int r = 0; r < PR; ++r) { acc[r][0] = zero4(); acc[r][1] = zero4(); }
+            {
+                f64x4 A[PR], B0, B1;
+#pragma unroll
+                for (int r = 0; r < PR; ++r) A[r] = ldg(c.ws, (r < nr) ? jc0 * NB + i0 + r : c.zb, lane);
+                B0 = ldg(c.ws, jc0 * NB + jc0, lane);
+                B1 = ldg(c.ws, c.zb, lane);                         // M_k,jc1 is zero for k = jc0 < jc1
+                for (int k = jc0; k < i0; ++k) {
+                    f64x4 nA[PR], nB0 = B0, nB1 = B1;
+#pragma unroll
+                    for (int r = 0; r < PR; ++r) nA[r] = A[r];
+                    if (k + 1 < i0) {
+#pragma unroll
+                        for (int r = 0; r < PR; ++r) nA[r] = ldg(c.ws, (r < nr) ? (k + 1) * NB + i0 + r : c.zb, lane);
+                        nB0 = ldg(c.ws, (k + 1) * NB + jc0, lane);
+                        nB1 = ldg(c.ws, (k + 1) * NB + jc1, lane);
+                    }
+#pragma unroll
+                    for (int r = 0; r < PR; ++r) { mma_blk(acc[r][0], A[r], B0); mma_blk(acc[r][1], A[r], B1); }
+#pragma unroll
+                    for (int r = 0; r < PR; ++r) A[r] = nA[r];
+                    B0 = nB0; B1 = nB1;
+                }
+            }
+            double ap0 = 0.0, ap1 = 0.0;
+#pragma unroll
+            for (int r = 0; r < PR; ++r) {
+                if (r < nr) {
+                    const int ir = i0 + r;
+                    const f64x4 Lop = ldg(c.ws, c.dT0 + ir, lane);
+                    f64x4 X0 = zero4(), X1 = zero4();
+                    mma_blk(X0, Lop, acc[r][0]);
+                    mma_blk(X1, Lop, acc[r][1]);
+                    X0 = -X0; X1 = -X1;
+                    stg(c.ws, ir * NB + jc0, lane, X0);
+                    stg(c.ws, ir * NB + jc1, lane, X1);
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const double zr = lds_d[c.L.z + BS * ir + rowof(rr, c.q)];
+                        ap0 = fma(X0[rr], zr, ap0);
+                        ap1 = fma(X1[rr], zr, ap1);
+                    }
+#pragma unroll
+                    for (int r2 = r + 1; r2 < PR; ++r2) {
+                        if (r2 < nr) {
+                            const f64x4 U = ldg(c.ws, ir * NB + i0 + r2, lane);
+                            mma_blk(acc[r2][0], U, X0);
+                            mma_blk(acc[r2][1], U, X1);
+                        }
+                    }
+                }
+            }
+            ap0 = qsum(ap0); ap1 = qsum(ap1);
+            if (c.q == 0) {                              // a column pair always belongs to the same wave: no race
+                lds_d[c.L.alpha + BS * jc0 + c.g] += ap0;
+                lds_d[c.L.alpha + BS * jc1 + c.g] += ap1;
+            }
+        }
+        // (2) the triangle inside the panel (one wave, the next in the round-robin of (1))
+        if (w == ((i0 >> 1) & (NW - 1))) {
+            for (int j = i0; j < i0 + nr; ++j) {
+                const f64x4 Mjj = ldg(c.ws, j * NB + j, lane);
+                double ap = 0.0;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) ap = fma(Mjj[rr], lds_d[c.L.z + BS * j + rowof(rr, c.q)], ap);
+                for (int i = j + 1; i < i0 + nr; ++i) {
+                    f64x4 acc = zero4();
+                    for (int k = j; k < i; ++k) {
+                        const f64x4 A = ldg(c.ws, k * NB + i, lane);        // U_ki
+                        const f64x4 B = ldg(c.ws, k * NB + j, lane);        // M_kj (k == j: diagonal slot)
+                        mma_blk(acc, A, B);
+                    }
+                    const f64x4 Lop = ldg(c.ws, c.dT0 + i, lane);
+                    f64x4 Mij = zero4();
+                    mma_blk(Mij, Lop, acc);
+                    Mij = -Mij;
+                    stg(c.ws, i * NB + j, lane, Mij);
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) ap = fma(Mij[rr], lds_d[c.L.z + BS * i + rowof(rr, c.q)], ap);
+                }
+                const double a = qsum(ap);
+                if (c.q == 0) lds_d[c.L.alpha + BS * j + c.g] += a;
+            }
+        }
+        __syncthreads();
+    }
 }
 
-// ---- phase 3: K^-1 blocks contracted with dK/dtheta
+// ---- phase 3: K^-1 blocks (K^-1)_ab = sum_{c>=a} M_ca^T M_cb, a >= b, contracted with dK/dtheta: 4 block rows a x
+// 2 block columns b per wave and step (the same 4 x 2 blocking; operands that would fall above the diagonal are the
+// zero block)
 template <int D, int KN>
 __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
     Shared* sh = reinterpret_cast<Shared*>(lds_d);
@@ -445,17 +517,49 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
 #pragma unroll
     for (int d = 0; d < D; ++d) accl[d] = 0.0;
     double accsf = 0.0, accsn = 0.0;
-    int pair = 0;
-    for (int a = 0; a < NB; ++a) {
-        for (int b = 0; b <= a; ++b, ++pair) {
-            if ((pair & (NW - 1)) != c.w) continue;
-            f64x4 acc = zero4();
-            for (int cc = a; cc < NB; ++cc) {
-                const f64x4 A = ldg(c.ws, cc * NB + a, lane);
-                const f64x4 B = ldg(c.ws, cc * NB + b, lane);
-                mma_blk(acc, A, B);
+    int item = 0;
+    for (int a0 = 0; a0 < NB; a0 += PR) {
+        const int na = min(PR, NB - a0);
+        for (int b0 = 0; b0 < a0 + na; b0 += 2, ++item) {
+            if ((item & (NW - 1)) != c.w) continue;
+            const bool hb1 = b0 + 1 < NB;
+            f64x4 acc[PR][2];
+#pragma unroll
+            for (int r = 0; r < PR; ++r) { acc[r][0] = zero4(); acc[r][1] = zero4(); }
+            {
+                // M_c,x is stored for c >= x only (c == x: diagonal slot); above the diagonal the slot holds U
+                f64x4 A[PR], B0, B1;
+#pragma unroll
+                for (int r = 0; r < PR; ++r) A[r] = ldg(c.ws, (r < na && a0 >= a0 + r) ? a0 * NB + a0 + r : c.zb, lane);
+                B0 = ldg(c.ws, (a0 >= b0) ? a0 * NB + b0 : c.zb, lane);
+                B1 = ldg(c.ws, (hb1 && a0 >= b0 + 1) ? a0 * NB + b0 + 1 : c.zb, lane);
+                for (int cc = a0; cc < NB; ++cc) {
+                    f64x4 nA[PR], nB0 = B0, nB1 = B1;
+#pragma unroll
+                    for (int r = 0; r < PR; ++r) nA[r] = A[r];
+                    if (cc + 1 < NB) {
+                        const int cn = cc + 1;
+#pragma unroll
+                        for (int r = 0; r < PR; ++r) nA[r] = ldg(c.ws, (r < na && cn >= a0 + r) ? cn * NB + a0 + r : c.zb, lane);
+                        nB0 = ldg(c.ws, (cn >= b0) ? cn * NB + b0 : c.zb, lane);
+                        nB1 = ldg(c.ws, (hb1 && cn >= b0 + 1) ? cn * NB + b0 + 1 : c.zb, lane);
+                    }
+#pragma unroll
+                    for (int r = 0; r < PR; ++r) { mma_blk(acc[r][0], A[r], B0); mma_blk(acc[r][1], A[r], B1); }
+#pragma unroll
+                    for (int r = 0; r < PR; ++r) A[r] = nA[r];
+                    B0 = nB0; B1 = nB1;
+                }
             }
-            contract<D, KN>(c, acc, a, b, (a == b) ? 1.0 : 2.0, accl, accsf, accsn);
+#pragma unroll
+            for (int r = 0; r < PR; ++r) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int a = a0 + r, b = b0 + n;
+                    if (r < na && b < NB && a >= b)
+                        contract<D, KN>(c, acc[r][n], a, b, (a == b) ? 1.0 : 2.0, accl, accsf, accsn);
+                }
+            }
         }
     }
     double v[D + 2];
