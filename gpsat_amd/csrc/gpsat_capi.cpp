@@ -197,12 +197,15 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     // fp32: two 4-wave workgroups per CU while a workgroup's LDS fits twice; beyond that one 8-wave workgroup per CU
     // (the 8-wave build of the same kernels), so that every SIMD still has two waves to overlap
     const bool w8 = !f64 && (gpsat::shared_bytes(D, NBmax) > 80 * 1024 || h->wg_per_cu == 1);
-    const size_t wsf = f64 ? gpsat::workspace_doubles_per_wg_f64(NBmax, PCcov)
+    // fp64: the same rule with the 4-wave / 8-wave builds of the fp64 kernels
+    const bool d4 = f64 && gpsat::shared_bytes_f64_w4(D, NBmax) <= 80 * 1024 && h->wg_per_cu != 1;
+    const size_t wsf = f64 ? (d4 ? gpsat::workspace_doubles_per_wg_f64_w4(NBmax, PCcov) : gpsat::workspace_doubles_per_wg_f64(NBmax, PCcov))
                            : (w8 ? gpsat::workspace_floats_per_wg_w8(NBmax, PCcov) : gpsat::workspace_floats_per_wg(NBmax, PCcov));
-    int grid = std::min(T, h->num_cu * h->wg_per_cu);
-    const size_t smem = f64 ? gpsat::shared_bytes_f64(D, NBmax) : (w8 ? gpsat::shared_bytes_w8(D, NBmax) : gpsat::shared_bytes(D, NBmax));
+    int grid = std::min(T, h->num_cu * (f64 ? 2 : h->wg_per_cu));
+    const size_t smem = f64 ? (d4 ? gpsat::shared_bytes_f64_w4(D, NBmax) : gpsat::shared_bytes_f64(D, NBmax))
+                            : (w8 ? gpsat::shared_bytes_w8(D, NBmax) : gpsat::shared_bytes(D, NBmax));
     if (smem > 160 * 1024) return fail(GPSAT_EINVAL, "tile too large for LDS");
-    if (w8 || f64) grid = std::min(grid, h->num_cu);
+    if (w8 || (f64 && !d4)) grid = std::min(grid, h->num_cu);
     if ((rc = h->ws.reserve((size_t)grid * wsf * esz))) return rc;
 
     const char *dX = nullptr, *dy = nullptr, *dXs = nullptr;
@@ -274,7 +277,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
 #endif
 
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-    HIP_TRY(f64 ? gpsat::launch_tiles_f64(D, a, grid, smem, h->stream)
+    HIP_TRY(f64 ? (d4 ? gpsat::launch_tiles_f64_w4(D, a, grid, smem, h->stream) : gpsat::launch_tiles_f64(D, a, grid, smem, h->stream))
                 : (w8 ? gpsat::launch_tiles_w8(D, a, grid, smem, h->stream) : gpsat::launch_tiles(D, a, grid, smem, h->stream)));
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
 

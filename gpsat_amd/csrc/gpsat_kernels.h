@@ -42,6 +42,10 @@ size_t shared_bytes(int D, int NBmax);
 size_t shared_bytes_f64(int D, int NBmax);
 size_t workspace_doubles_per_wg_f64(int NBmax, int PCcov);
 hipError_t launch_tiles_f64(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream);
+// 4-wave build (gpsat_kernels_f64.hip -DGPSAT_F64_W4): two workgroups per CU for tiles whose LDS fits twice
+size_t shared_bytes_f64_w4(int D, int NBmax);
+size_t workspace_doubles_per_wg_f64_w4(int NBmax, int PCcov);
+hipError_t launch_tiles_f64_w4(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream);
 size_t workspace_floats_per_wg(int NBmax, int PCcov);     // PCcov: prediction chunks kept for f_cov (0 = none)
 hipError_t launch_tiles(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream);
 // 8-wave build of the same kernels (gpsat_kernels.hip -DGPSAT_W8): used when a workgroup needs more than half of the LDS

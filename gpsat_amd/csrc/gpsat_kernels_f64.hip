@@ -16,7 +16,20 @@
 #include "gpsat_kernels.h"
 
 namespace gpsat {
-namespace f64k {
+// Two builds are linked (as for the fp32 kernels): the default, 8 waves per workgroup and one workgroup per CU, and
+// -DGPSAT_F64_W4, 4 waves and two workgroups per CU for tiles whose LDS fits twice (a second TILE per CU overlaps the
+// serial diagonal work of the first).
+#ifdef GPSAT_F64_W4
+#define GPSAT_F64_NW 4
+#define F64NS f64k4
+#define F64FN(name) name##_w4
+#define F64_MIN_WG 2
+#else
+#define F64NS f64k
+#define F64FN(name) name
+#define F64_MIN_WG 1
+#endif
+namespace F64NS {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -762,7 +775,7 @@ __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const double* __rest
 }
 
 template <int D, int KN>
-__global__ void __launch_bounds__(NT, 1) gp_tile_kernel_f64(const KernelArgs A) {
+__global__ void __launch_bounds__(NT, F64_MIN_WG) gp_tile_kernel_f64(const KernelArgs A) {
     constexpr int H = D + 2;
     Ctx<D, KN> c;
     c.tid = threadIdx.x;
@@ -923,25 +936,25 @@ static hipError_t launch_d(const KernelArgs& a, int grid, size_t smem, hipStream
     }
 }
 
-}  // namespace f64k
+}  // namespace F64NS
 
-size_t shared_bytes_f64(int D, int NBmax) {
-    const size_t NP = (size_t)NBmax * f64k::BS;
-    const size_t dbl = (sizeof(f64k::Shared) + 15) / 16 * 2 + D * NP + 3 * NP + f64k::BLK + 16 * 17 + 16 + 10 * f64k::BLK + 4 * f64k::BS + 2;
+size_t F64FN(shared_bytes_f64)(int D, int NBmax) {
+    const size_t NP = (size_t)NBmax * F64NS::BS;
+    const size_t dbl = (sizeof(F64NS::Shared) + 15) / 16 * 2 + D * NP + 3 * NP + F64NS::BLK + 16 * 17 + 16 + 10 * F64NS::BLK + 4 * F64NS::BS + 2;
     return (dbl * sizeof(double) + 15) & ~size_t(15);
 }
 
-size_t workspace_doubles_per_wg_f64(int NBmax, int PCcov) {
+size_t F64FN(workspace_doubles_per_wg_f64)(int NBmax, int PCcov) {
     // + V of all prediction chunks when the full covariance is wanted (spare chunks: a wave always solves 2 at a time)
     const size_t cov = PCcov > 0 ? (size_t)(PCcov + 3) * NBmax : 0;
-    return (size_t)f64k::BLK * ((size_t)NBmax * NBmax + (size_t)NBmax + (size_t)f64k::NW * 4 * NBmax + cov + 1);
+    return (size_t)F64NS::BLK * ((size_t)NBmax * NBmax + (size_t)NBmax + (size_t)F64NS::NW * 4 * NBmax + cov + 1);
 }
 
-hipError_t launch_tiles_f64(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream) {
+hipError_t F64FN(launch_tiles_f64)(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream) {
     switch (D) {
-        case 1: return f64k::launch_d<1>(a, grid, smem, stream);
-        case 2: return f64k::launch_d<2>(a, grid, smem, stream);
-        case 3: return f64k::launch_d<3>(a, grid, smem, stream);
+        case 1: return F64NS::launch_d<1>(a, grid, smem, stream);
+        case 2: return F64NS::launch_d<2>(a, grid, smem, stream);
+        case 3: return F64NS::launch_d<3>(a, grid, smem, stream);
         default: return hipErrorInvalidValue;
     }
 }
