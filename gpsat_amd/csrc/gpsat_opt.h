@@ -155,8 +155,16 @@ static __device__ __noinline__ void ls_step(Shared* sh, int H, int max_ls) {
             sh->t_hi = sh->t_prev; sh->f_hi = sh->f_prev; sh->dphi_hi = sh->dphi_prev;
             sh->ls_phase = 1;
         } else {
+            // not bracketed yet (sufficient decrease, still descending): extrapolate as More-Thuente / SciPy's dcsrch do --
+            // the cubic through the last two points when its minimiser lies ahead, safeguarded to
+            // [t + 1.1 (t - t_prev), t + 4 (t - t_prev)]
+            const double tp = sh->t_prev, dt = t - tp;
+            double tn = cubic_min(tp, sh->f_prev, sh->dphi_prev, t, ft, dphit);
+            const double lo_b = t + 1.1 * dt, hi_b = t + 4.0 * dt;
+            if (!(tn > lo_b)) tn = hi_b;          // minimiser behind us or undefined: the cubic has no minimum ahead
+            tn = fmin(tn, hi_b);
             sh->t_prev = t; sh->f_prev = ft; sh->dphi_prev = dphit;
-            sh->t = 2.0 * t;
+            sh->t = tn;
             return;
         }
     } else {
