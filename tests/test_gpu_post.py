@@ -136,3 +136,66 @@ def test_glue_large_properties(eng):
     g2 = glue_local_predictions_2d(df.sample(frac=1.0, random_state=1), ["pred_loc_x", "pred_loc_y"], ["x", "y"],
                                    ["f*", "v"], 300.0, engine=eng)
     np.testing.assert_allclose(g2.values, g.values, rtol=1e-12, atol=1e-14)
+
+
+def test_fit_smooth_predict_glue_production_loop(eng, tmp_path):
+    """The production loop either side of the GP engine: fit on a grid of experts -> smooth the
+    hyper-parameter fields on the device -> predict-only re-run with the smoothed parameters loaded per tile
+    (optimise=False) -> glue the overlapping predictions on the device.  Checks the plumbing (tables, suffixes, loaded
+    values) and that the glued field reproduces the truth."""
+    from gpsat_amd.local_experts import BatchedLocalExpertOI, ResultStore
+    from gpsat_amd.postprocessing import smooth_hyperparameters, glue_local_predictions_2d
+    rng = np.random.default_rng(0)
+    M = 6000
+    xy = rng.uniform(-1.0, 1.0, (M, 2))
+    truth = lambda x, y: np.sin(3 * x) * np.cos(2 * y)
+    df = pd.DataFrame({"x": xy[:, 0], "y": xy[:, 1], "obs": truth(xy[:, 0], xy[:, 1]) + 0.05 * rng.standard_normal(M)})
+    gx, gy = np.meshgrid(np.linspace(-0.6, 0.6, 4), np.linspace(-0.6, 0.6, 4))
+    xprt = pd.DataFrame({"x": gx.ravel(), "y": gy.ravel()})
+    px, py = np.meshgrid(np.linspace(-0.7, 0.7, 29), np.linspace(-0.7, 0.7, 29))
+    pred_df = pd.DataFrame({"x": px.ravel(), "y": py.ravel()})
+    r_train, r_pred = 0.35, 0.3
+    common = dict(
+        expert_loc_config={"source": xprt},
+        data_config={"data_source": df, "obs_col": ["obs"], "coords_col": ["x", "y"],
+                     "local_select": [{"col": ["x", "y"], "comp": "<", "val": r_train}]},
+        pred_loc_config={"method": "from_dataframe", "df": pred_df, "max_dist": r_pred}, engine=eng)
+    model = {"oi_model": "HipGPRModel", "init_params": {"kernel": "Matern32", "obs_mean": "local"},
+             "constraints": {"lengthscales": {"low": [1e-3, 1e-3], "high": [5.0, 5.0]}}}
+    store = str(tmp_path / "store")
+    tabs = BatchedLocalExpertOI(model_config=model, **common).run(store_path=store)
+    assert len(tabs["run_details"]) == 16 and tabs["run_details"]["num_obs"].min() > 300
+    # smooth all three hyper-parameter fields; values are clipped first
+    cfg = {"lengthscales": {"l_x": 0.5, "l_y": 0.5, "max": 4.0}, "kernel_variance": {"l_x": 0.5, "l_y": 0.5},
+           "likelihood_variance": {"l_x": 0.5, "l_y": 0.5, "min": 1e-4}}
+    sm = smooth_hyperparameters(store, list(cfg), cfg, xy_dims=["x", "y"], engine=eng)
+    ls, ls_s = tabs["lengthscales"], sm["lengthscales_SMOOTHED"]
+    assert len(ls_s) == len(ls) and ls_s["lengthscales"].std() < ls["lengthscales"].std()
+    assert ResultStore(store).read("kernel_variance_SMOOTHED") is not None
+    # predict-only with the smoothed parameters loaded per expert location
+    model2 = dict(model, load_params={"file": store, "table_suffix": "_SMOOTHED"})
+    tabs2 = BatchedLocalExpertOI(model_config=model2, **common).run(store_path=store, optimise=False, table_suffix="_SMOOTHED")
+    rd = tabs2["run_details_SMOOTHED"] if "run_details_SMOOTHED" in tabs2 else tabs2["run_details"]
+    assert len(rd) == 16 and not rd["optimise_success"].any()                   # optimise=False => success False
+    # loading from the same store + suffix without optimising: the parameter tables are NOT re-written
+    # (local_experts.py:1090-1097); the smoothed tables stay as they were
+    assert len(tabs2["lengthscales_SMOOTHED"]) == 0
+    pd.testing.assert_frame_equal(ResultStore(store).read("lengthscales_SMOOTHED"), ls_s)
+    # the loaded values were used: the objective of expert 5 equals that of a stand-alone model with the smoothed values
+    from gpsat_amd.models import HipGPRModel
+    loc = xprt.iloc[5]
+    sel = df[(df["x"] - loc["x"]) ** 2 + (df["y"] - loc["y"]) ** 2 <= r_train * r_train]
+    m = HipGPRModel(data=sel, obs_col="obs", coords_col=["x", "y"], obs_mean="local", kernel="Matern32", engine=eng)
+    key = (loc["x"], loc["y"])
+    m.set_parameters(lengthscales=ls_s.loc[[key]].sort_values("_dim_0")["lengthscales"].values,
+                     kernel_variance=float(sm["kernel_variance_SMOOTHED"].loc[[key]]["kernel_variance"].values[0]),
+                     likelihood_variance=float(sm["likelihood_variance_SMOOTHED"].loc[[key]]["likelihood_variance"].values[0]))
+    assert rd.loc[[key]]["num_obs"].values[0] == len(sel)
+    assert m.get_objective_function_value() == pytest.approx(rd.loc[[key]]["objective_value"].values[0], rel=1e-5, abs=1e-3)
+    preds = (tabs2["preds_SMOOTHED"] if "preds_SMOOTHED" in tabs2 else tabs2["preds"]).reset_index()
+    preds["f"] = preds["f*"] + preds["f_bar"]
+    glued = glue_local_predictions_2d(preds, ["pred_loc_x", "pred_loc_y"], ["x", "y"], ["f", "f*_var"], r_pred, engine=eng)
+    assert len(glued) == len(preds.drop_duplicates(["pred_loc_x", "pred_loc_y"]))
+    err = glued["f"].values - truth(glued["pred_loc_x"].values, glued["pred_loc_y"].values)
+    assert np.sqrt(np.mean(err ** 2)) < 0.03                                        # noise 0.05, ~700 obs per expert
+    assert (glued["f*_var"].values > 0).all()
