@@ -25,8 +25,9 @@ Supported config subset (anything else raises ``NotImplementedError`` -- never a
   model_config      : {"oi_model": "HipGPRModel" | "GPflowGPRModel" | {"path_to_model", "model_name"},
                        "init_params", "constraints", "optim_kwargs", "pred_kwargs", "params_to_store",
                        "load_params": {"file": store dir | dict of tables, "table_suffix": str}}
-``load_params.previous=True`` (an exponential moving average of earlier tiles' optima, a serial cross-tile
-dependency, local_experts.py:1200-1217) and ``replacement_*`` models are rejected explicitly.
+``replacement_*`` model settings for tiles below ``replacement_threshold`` observations are honoured (one engine call
+per model profile).  ``load_params.previous=True`` (an exponential moving average of earlier tiles' optima, a serial cross-tile
+dependency, local_experts.py:1200-1217) is rejected explicitly.
 """
 from __future__ import annotations
 
@@ -270,15 +271,32 @@ class BatchedLocalExpertOI:
         name = om["model_name"] if isinstance(om, dict) else om
         if name not in ("HipGPRModel", "GPflowGPRModel"):
             raise NotImplementedError(f"oi_model '{name}': the batched backend builds the exact-GP expert only")
-        for k in model_config:
-            if k.startswith("replacement_"):
-                raise NotImplementedError("replacement_* models are not supported by the batched backend")
         self.init_params = dict(model_config.get("init_params") or {})
         self.constraints = model_config.get("constraints")
         self.optim_kwargs = dict(model_config.get("optim_kwargs") or {})
         self.pred_kwargs = dict(model_config.get("pred_kwargs") or {})
-        if self.pred_kwargs.get("full_cov"):
-            raise NotImplementedError("full_cov=True is not built in the HIP backend")
+        # replacement model for tiles with fewer than `replacement_threshold` observations (local_experts.py:339-346,
+        # 1021-1041): same defaults as the reference -- init_params / constraints fall back to the main ones,
+        # optim_kwargs / pred_kwargs to {}
+        self.replacement_threshold = model_config.get("replacement_threshold")
+        self.profiles = {"main": dict(init_params=self.init_params, constraints=self.constraints,
+                                      optim_kwargs=self.optim_kwargs, pred_kwargs=self.pred_kwargs)}
+        if self.replacement_threshold is not None:
+            rm = model_config.get("replacement_model")
+            rname = rm["model_name"] if isinstance(rm, dict) else rm
+            if rname not in (None, "HipGPRModel", "GPflowGPRModel"):
+                raise NotImplementedError(f"replacement_model '{rname}': the batched backend builds the exact-GP expert only")
+            rip = model_config.get("replacement_init_params")
+            rco = model_config.get("replacement_constraints")
+            self.profiles["replacement"] = dict(
+                init_params=self.init_params if rip is None else dict(rip),
+                constraints=self.constraints if rco is None else rco,
+                optim_kwargs=dict(model_config.get("replacement_optim_kwargs") or {}),
+                pred_kwargs=dict(model_config.get("replacement_pred_kwargs") or {}))
+        for pf in self.profiles.values():
+            if pf["pred_kwargs"].get("full_cov"):
+                raise NotImplementedError("full_cov=True tables are not written by the batched orchestrator "
+                                          "(use HipGPRModel.predict(full_cov=True) / Engine.fit_predict_batch(full_cov=True))")
         self.params_to_store = model_config.get("params_to_store") or PARAM_NAMES
         self.load_params = model_config.get("load_params")
         if self.load_params is not None and self.load_params.get("previous", False):
@@ -293,9 +311,9 @@ class BatchedLocalExpertOI:
         self.device_select = device_select
 
     # -- per-tile host-side model logic reuses the drop-in class (intake, scaling, defaults, constraints)
-    def _host_model(self, df_local):
+    def _host_model(self, df_local, init_params=None):
         return HipGPRModel(data=df_local, obs_col=self.obs_col, coords_col=self.coords_col, engine=self.engine,
-                           verbose=False, **self.init_params)
+                           verbose=False, **(self.init_params if init_params is None else init_params))
 
     def _loaded_params(self, store: ResultStore, suffix, ref_row, model):
         """load_params from tables ``<param><suffix>`` where the index equals the expert coordinates
@@ -349,13 +367,16 @@ class BatchedLocalExpertOI:
         if self.device_select and len(self.local_select):
             dev_off, dev_idx = DeviceSelector(self.df, self.local_select, self.engine).select(xl)
         D = len(cc)
-        kernel = self.init_params.get("kernel", "Matern32")
-        if kernel not in L.KERNEL_IDS:
-            raise NotImplementedError(f"kernel {kernel!r}")
-        fixed = list(self.optim_kwargs.get("fixed_params") or [])
-        max_iter = int(self.optim_kwargs.get("max_iter", 10_000))
-        eng_kw = {k: self.optim_kwargs[k] for k in ("max_ls", "ftol", "gtol", "adam_lr") if k in self.optim_kwargs}
-        optimiser = self.optim_kwargs.get("optimiser", "lbfgs") if optimise else "none"
+        # per profile (main / replacement): what one engine call needs to be uniform in
+        prof = {}
+        for pname, pf in self.profiles.items():
+            kernel = pf["init_params"].get("kernel", "Matern32")
+            if kernel not in L.KERNEL_IDS:
+                raise NotImplementedError(f"kernel {kernel!r}")
+            ok = pf["optim_kwargs"]
+            prof[pname] = dict(kernel=kernel, fixed=list(ok.get("fixed_params") or []), max_iter=int(ok.get("max_iter", 10_000)),
+                               eng_kw={k: ok[k] for k in ("max_ls", "ftol", "gtol", "adam_lr") if k in ok},
+                               optimiser=ok.get("optimiser", "lbfgs") if optimise else "none", **pf)
 
         # ---------------- pass 1: selection + host-side model logic for every expert (fp64) ----------------
         tiles, stubs = [], []
@@ -371,7 +392,10 @@ class BatchedLocalExpertOI:
             if len(df_local) < min_obs:                        # local_experts.py:988-1012: stub run_details row
                 stubs.append((loc, len(df_local)))
                 continue
-            m = self._host_model(df_local)
+            pname = "replacement" if (self.replacement_threshold is not None and
+                                      len(df_local) < self.replacement_threshold) else "main"   # local_experts.py:1021-1041
+            pf = prof[pname]
+            m = self._host_model(df_local, pf["init_params"])
             save_params = True
             if self.load_params is not None:
                 if not self._loaded_params(store, table_suffix, ref, m):
@@ -380,61 +404,67 @@ class BatchedLocalExpertOI:
                         self.load_params.get("table_suffix", table_suffix) == table_suffix and
                         set(self.load_params) <= {"file", "table_suffix"})
                 save_params = not (same and not optimise)      # local_experts.py:1090-1097
-            if self.constraints is not None:
-                cons = {k: dict(v) for k, v in self.constraints.items()}
-                if self.init_params.get("coords_scale", None) is not None and "lengthscales" in cons:
+            if pf["constraints"] is not None:
+                cons = {k: dict(v) for k, v in pf["constraints"].items()}
+                if pf["init_params"].get("coords_scale", None) is not None and "lengthscales" in cons:
                     cons["lengthscales"]["scale"] = True       # local_experts.py:1113-1114
                 m.set_parameter_constraints(cons, move_within_tol=True, tol=1e-2)
-            m._fix_hyperparameters(fixed)
-            pcs = pc / m.coords_scale if self.pred_kwargs.get("apply_scale", True) else pc
-            tiles.append(dict(loc=loc, model=m, pred_raw=pc, pred_scaled=pcs, save_params=save_params))
+            m._fix_hyperparameters(pf["fixed"])
+            pcs = pc / m.coords_scale if pf["pred_kwargs"].get("apply_scale", True) else pc
+            tiles.append(dict(loc=loc, model=m, pred_raw=pc, pred_scaled=pcs, save_params=save_params, profile=pname))
 
-        # ---------------- pass 2: one packed batch per wave through the C ABI ----------------
+        # ---------------- pass 2: one packed batch per wave (and per model profile) through the C ABI ----------------
         out = {k: [] for k in ("run_details", "preds", *self.params_to_store)}
-        wave = max_tiles_per_call or max(len(tiles), 1)
-        for w0 in range(0, len(tiles), wave):
-            tw = tiles[w0:w0 + wave]
-            t0 = time.perf_counter()
-            Ns = np.array([len(t["model"].coords) for t in tw])
-            Ps = np.array([len(t["pred_scaled"]) if predict else 0 for t in tw])
-            obs_off = np.concatenate([[0], np.cumsum(Ns)])
-            pred_off = np.concatenate([[0], np.cumsum(Ps)])
-            X = np.concatenate([t["model"].coords for t in tw]).astype(np.float32)
-            y = np.concatenate([t["model"].obs[:, 0] for t in tw]).astype(np.float32)
-            Xs = np.concatenate([t["pred_scaled"] if predict else np.zeros((0, D)) for t in tw]).astype(np.float32)
-            theta0 = np.stack([t["model"]._theta for t in tw])
-            lo = np.stack([t["model"]._lo for t in tw])
-            hi = np.stack([t["model"]._hi for t in tw])
-            trainable = tw[0]["model"]._trainable
-            r = self.engine.fit_predict_batch(D=D, obs_off=obs_off, X=X, y=y, pred_off=pred_off, Xs=Xs, theta0=theta0,
-                                              lo=lo, hi=hi, trainable=trainable, kernel=kernel, optimiser=optimiser,
-                                              max_iter=max_iter, **eng_kw)
-            dt = (time.perf_counter() - t0) / max(len(tw), 1)
-            for k, t in enumerate(tw):
-                m = t["model"]
-                loc = t["loc"]
-                idx1 = _index_for(cc, loc[None, :])
-                out["run_details"].append(pd.DataFrame({
-                    "_dim_0": [0], "num_obs": [int(Ns[k])], "run_time": [dt], "objective_value": [float(r.nll[k])],
-                    "parameters_optimised": [bool(optimise)], "optimise_success": [bool(optimise and r.status[k] == 0)],
-                    "model": [f"{HipGPRModel.__module__}.{HipGPRModel.__name__}"[:64]],
-                    "device": [str(m.gpu_name)[:64]], "config_id": [config_id]}, index=idx1))
-                if t["save_params"]:
-                    th = r.theta[k]
-                    vals = {"lengthscales": th[:D], "kernel_variance": th[D:D + 1], "likelihood_variance": th[D + 1:D + 2]}
-                    for pn in self.params_to_store:
-                        v = np.asarray(vals[pn], dtype=np.float64)
-                        out[pn].append(pd.DataFrame({"_dim_0": np.arange(len(v)), pn: v},
-                                                    index=_index_for(cc, np.repeat(loc[None, :], len(v), 0))))
-                if predict and Ps[k] > 0:
-                    a, b = pred_off[k], pred_off[k + 1]
-                    P = int(Ps[k])
-                    pr = {"_dim_0": np.arange(P), "f*": r.f_mean[a:b].astype(np.float64),
-                          "f*_var": r.f_var[a:b].astype(np.float64), "y_var": r.y_var[a:b].astype(np.float64),
-                          "f_bar": np.repeat(m.obs_mean[:, 0], P)}
-                    for ci, c_ in enumerate(cc):
-                        pr[f"pred_loc_{c_}"] = t["pred_raw"][:, ci]
-                    out["preds"].append(pd.DataFrame(pr, index=_index_for(cc, np.repeat(loc[None, :], P, 0))))
+        res = [None] * len(tiles)                 # per tile: (theta, nll, status, f_mean, f_var, y_var, seconds)
+        for pname, pf in prof.items():
+            members = [i for i, t in enumerate(tiles) if t["profile"] == pname]
+            wave = max_tiles_per_call or max(len(members), 1)
+            for w0 in range(0, len(members), wave):
+                ids = members[w0:w0 + wave]
+                tw = [tiles[i] for i in ids]
+                t0 = time.perf_counter()
+                Ns = np.array([len(t["model"].coords) for t in tw])
+                Ps = np.array([len(t["pred_scaled"]) if predict else 0 for t in tw])
+                obs_off = np.concatenate([[0], np.cumsum(Ns)])
+                pred_off = np.concatenate([[0], np.cumsum(Ps)])
+                X = np.concatenate([t["model"].coords for t in tw]).astype(np.float32)
+                y = np.concatenate([t["model"].obs[:, 0] for t in tw]).astype(np.float32)
+                Xs = np.concatenate([t["pred_scaled"] if predict else np.zeros((0, D)) for t in tw]).astype(np.float32)
+                theta0 = np.stack([t["model"]._theta for t in tw])
+                lo = np.stack([t["model"]._lo for t in tw])
+                hi = np.stack([t["model"]._hi for t in tw])
+                trainable = tw[0]["model"]._trainable
+                r = self.engine.fit_predict_batch(D=D, obs_off=obs_off, X=X, y=y, pred_off=pred_off, Xs=Xs, theta0=theta0,
+                                                  lo=lo, hi=hi, trainable=trainable, kernel=pf["kernel"],
+                                                  optimiser=pf["optimiser"], max_iter=pf["max_iter"], **pf["eng_kw"])
+                dt = (time.perf_counter() - t0) / max(len(tw), 1)
+                for k, i in enumerate(ids):
+                    a_, b_ = pred_off[k], pred_off[k + 1]
+                    res[i] = (r.theta[k], float(r.nll[k]), int(r.status[k]), r.f_mean[a_:b_], r.f_var[a_:b_], r.y_var[a_:b_], dt)
+        for t, rr in zip(tiles, res):              # tables in expert order, whatever the grouping above
+            th, nll_k, st_k, fm, fv, yv, dt = rr
+            m = t["model"]
+            loc = t["loc"]
+            idx1 = _index_for(cc, loc[None, :])
+            out["run_details"].append(pd.DataFrame({
+                "_dim_0": [0], "num_obs": [len(m.coords)], "run_time": [dt], "objective_value": [nll_k],
+                "parameters_optimised": [bool(optimise)], "optimise_success": [bool(optimise and st_k == 0)],
+                "model": [f"{HipGPRModel.__module__}.{HipGPRModel.__name__}"[:64]],
+                "device": [str(m.gpu_name)[:64]], "config_id": [config_id]}, index=idx1))
+            if t["save_params"]:
+                vals = {"lengthscales": th[:D], "kernel_variance": th[D:D + 1], "likelihood_variance": th[D + 1:D + 2]}
+                for pn in self.params_to_store:
+                    v = np.asarray(vals[pn], dtype=np.float64)
+                    out[pn].append(pd.DataFrame({"_dim_0": np.arange(len(v)), pn: v},
+                                                index=_index_for(cc, np.repeat(loc[None, :], len(v), 0))))
+            P = len(fm) if predict else 0
+            if P > 0:
+                pr = {"_dim_0": np.arange(P), "f*": np.asarray(fm, dtype=np.float64),
+                      "f*_var": np.asarray(fv, dtype=np.float64), "y_var": np.asarray(yv, dtype=np.float64),
+                      "f_bar": np.repeat(m.obs_mean[:, 0], P)}
+                for ci, c_ in enumerate(cc):
+                    pr[f"pred_loc_{c_}"] = t["pred_raw"][:, ci]
+                out["preds"].append(pd.DataFrame(pr, index=_index_for(cc, np.repeat(loc[None, :], P, 0))))
         for loc, n in stubs:
             out["run_details"].append(pd.DataFrame({
                 "_dim_0": [0], "num_obs": [int(n)], "run_time": [np.nan], "objective_value": [np.nan],

@@ -167,6 +167,33 @@ def test_unsupported_configs_fail_loudly():
     with pytest.raises(NotImplementedError):
         BatchedLocalExpertOI(engine=OracleEngine(), **bad)
     bad = dict(base)
-    bad["model_config"] = {**base["model_config"], "replacement_threshold": 10}
+    bad["model_config"] = {**base["model_config"], "replacement_threshold": 10, "replacement_model": "GPflowSGPRModel"}
     with pytest.raises(NotImplementedError):
         BatchedLocalExpertOI(engine=OracleEngine(), **bad)
+
+
+def test_replacement_model_for_small_tiles(tmp_path):
+    """Tiles with fewer than `replacement_threshold` observations run with the replacement settings
+    (GPSat/local_experts.py:339-346,1021-1041): here another covariance function and a fixed lengthscale; one engine
+    call per profile, tables in expert order."""
+    df, X_grid, noise_std = _notebook_data()
+    cfg = _configs(df, X_grid, 0.1, [0.2, 0.3, 0.4, 0.5], noise_std)          # 41 / 37 / 44 / 38 observations
+    cfg["model_config"] = {**cfg["model_config"], "replacement_threshold": 40,
+                           "replacement_init_params": {"kernel": "Matern32", "noise_variance": noise_std ** 2,
+                                                       "kernel_kwargs": {"lengthscales": [0.07]}},
+                           "replacement_optim_kwargs": {"fixed_params": ["lengthscales", "likelihood_variance"]}}
+    eng = OracleEngine()
+    oi = BatchedLocalExpertOI(engine=eng, **cfg)
+    tabs = oi.run(store_path=str(tmp_path / "s"))
+    assert [c["T"] for c in eng.calls] == [2, 2]                                 # main profile, replacement profile
+    rd = tabs["run_details"]
+    assert rd.index.tolist() == [0.2, 0.3, 0.4, 0.5] and rd["num_obs"].tolist() == [41, 37, 44, 38]
+    ls = tabs["lengthscales"]["lengthscales"]
+    assert ls.loc[0.3] == pytest.approx(0.07) and ls.loc[0.5] == pytest.approx(0.07)      # fixed in the replacement
+    assert abs(ls.loc[0.2] - 0.03354575999266631) < 1e-5 and abs(ls.loc[0.4] - 0.1793349088554155) < 1e-5
+    # the replacement tiles really used Matern-3/2: their objective equals the oracle's Matern-3/2 objective
+    m = (df["x"] <= 0.3 + 0.1) & (df["x"] >= 0.3 - 0.1)
+    d = df.loc[m]
+    o = go.OracleGPR(d[["x"]].values, d[["y"]].values, kernel="Matern32", noise_variance=noise_std ** 2)
+    o.set_parameters(lengthscales=[0.07], kernel_variance=float(tabs["kernel_variance"]["kernel_variance"].loc[0.3]))
+    assert o.get_objective_function_value() == pytest.approx(rd["objective_value"].loc[0.3], abs=1e-4)   # fp32-packed inputs
