@@ -105,6 +105,103 @@ def cpu_baseline(X, y, Xs, N, P, D, kid, max_iter, n_tiles, workers):
     return n_tiles / wall, float(np.mean([r[1] for r in res])), wall
 
 
+def other_workload(a):
+    """The other single-GPU shapes of BASELINE.json as non-default bench lines (same timing protocol; prototype tiles
+    per size class are generated once and replicated -- the arithmetic does not depend on the values)."""
+    from gpsat_amd import synthetic as syn
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    D, P = 3, 500
+    if a.workload == "configs2":
+        T = a.tiles if a.tiles != 4096 else 1024
+        kid, kernel, dtype, np_dt, optimiser, max_iter = 2, "Matern32", "f32", np.float32, "lbfgs", a.max_iter
+        sizes = [128, 256, 384, 512, 768, 1024, 1536, 2048]
+        Ns = np.random.default_rng(rank).choice(sizes, T)
+        proto = {n: [syn.make_tile(100 + 10 * i + j, n, P, D, kid) for j in range(2)] for i, n in enumerate(sizes)}
+        parts = [proto[int(n)][t % 2] for t, n in enumerate(Ns)]
+        theta0 = np.ones((T, D + 2))
+        lo, hi = syn.default_bounds(T, D)
+        name = "BASELINE.json configs[2]: ragged tiles N in {128..2048}, Matern-3/2, 3D inputs, fp32"
+        peak = PEAK_F32_MFMA_TFLOPS
+    else:
+        T = a.tiles if a.tiles != 4096 else 1024
+        kid, kernel, dtype, np_dt, optimiser, max_iter = 0, "RBF", "f64", np.float64, "none", 0
+        Ns = np.full(T, 2000)
+        proto = [syn.make_tile(1 + j, 2000, P, D, kid) for j in range(8)]
+        parts = [proto[t % 8] for t in range(T)]
+        theta0 = np.stack([pp[3] for pp in parts])          # the generating hyper-parameters stand in for the smoothed ones
+        lo = hi = None
+        name = "BASELINE.json configs[4] per GPU: fp64, N=2000, predict-only with given hyper-parameters"
+        peak = 78.6                                         # fp64 MFMA, MI355X_MICROARCH.md
+    X = np.concatenate([pp[0] for pp in parts]).astype(np_dt)
+    y = np.concatenate([pp[1] for pp in parts]).astype(np_dt)
+    Xs = np.concatenate([pp[2] for pp in parts]).astype(np_dt)
+    obs_off = np.concatenate([[0], np.cumsum(Ns)])
+    pred_off = np.arange(T + 1) * P
+
+    import torch
+    import torch.distributed as dist
+    from gpsat_amd.engine import Engine
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    dX, dy, dXs = (torch.from_numpy(v).to(dev) for v in (X, y, Xs))
+    eng = Engine(local_rank)
+    kw = dict(D=D, obs_off=obs_off, X=dX, y=dy, pred_off=pred_off, Xs=dXs, theta0=theta0, kernel=kernel, optimiser=optimiser,
+              max_iter=max_iter, dtype=dtype)
+    if lo is not None:
+        kw.update(lo=lo, hi=hi)
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        eng.fit_predict_batch(**kw)
+    barrier()
+    t0 = time.perf_counter()
+    kms = []
+    for _ in range(a.steps):
+        r = eng.fit_predict_batch(**kw)
+        kms.append(r.kernel_ms)
+    barrier()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        Nf = Ns.astype(np.float64)
+        if a.workload == "configs2":
+            flops = float((r.n_eval * f_eval(Nf, D) + f_pred(Nf, P, D)).sum())
+        else:
+            flops = float((f_nll(Nf, D) + f_pred(Nf, P, D)).sum())
+        k_ms = float(np.mean(kms))
+        ach = flops / (k_ms * 1e-3) / 1e12
+        print(json.dumps({
+            "metric": "local-expert tiles/sec (fit+predict)", "value": round(T * world * a.steps / dt, 2), "unit": "tiles/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+            "data": "synthetic (prototype tiles per size class, replicated)",
+            "config": {"workload": name, "tiles_per_gpu": int(T), "mean_obs_per_tile": float(Nf.mean()), "pred_per_tile": P,
+                       "dim": D, "kernel": kernel, "optimiser": optimiser, "max_iter": max_iter,
+                       "evals_per_tile": round(float(r.n_eval.mean()), 2), "failed_tiles": int(np.sum((r.status == 2) | (r.status == 3))),
+                       "parallelism": f"tile-sharded x{world}", "device": eng.device_name},
+            "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(ach / peak, 4), "traffic": None, "kernel_ms": round(k_ms, 3), "flops_per_launch": flops},
+        }), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,7 +218,12 @@ def main():
     ap.add_argument("--wg-per-cu", type=int, default=0)
     ap.add_argument("--workers", type=int, default=0, help="host processes for data generation / CPU baseline "
                     "(0 = auto; use 1 under rocprofv3 --pmc: no fork beside the profiler)")
+    ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs4"],
+                    help="BASELINE.json configs[i]: 1 = the metric's workload (default); 2 = ragged N in {128..2048}, "
+                         "Matern-3/2, fp32; 4 = fp64, N = 2000, predict-only with given hyper-parameters")
     a = ap.parse_args()
+    if a.workload != "configs1":
+        return other_workload(a)
 
     from gpsat_amd import _lib as L
     from gpsat_amd import synthetic as syn
