@@ -11,7 +11,8 @@ from oracle import gp_oracle as go
 
 names = {0: "RBF", 1: "Matern12", 2: "Matern32", 3: "Matern52"}
 rng = np.random.default_rng(int(os.environ.get("SEED", 1)))
-engines = {1: Engine(0, workgroups_per_cu=1), 2: Engine(0, workgroups_per_cu=2)}
+wgs = [int(v) for v in os.environ.get("FUZZ_WG", "1,2").split(",")]
+engines = {v: Engine(0, workgroups_per_cu=v) for v in wgs}
 worst = {}
 bad = 0
 t_start = time.time()
@@ -23,7 +24,7 @@ for case in range(n_cases):
     if rng.random() < 0.08:
         Ns[0] = int(rng.choice([900, 1024, 1300, 2048]))          # one workgroup per CU (LDS), long sweeps
     Ps = [int(rng.choice([0, 1, 15, 16, 17, 31, 32, 33, 64, 65, 100, 130])) for _ in range(T)]
-    wg = int(rng.choice([1, 2]))
+    wg = int(rng.choice(wgs))
     cov = rng.random() < 0.3
     np_dt = np.float32 if dtype == "f32" else np.float64
     b = syn.make_batch(T, Ns, Ps, D, kid, base_seed=int(rng.integers(0, 10**6)), dtype=np_dt)
