@@ -13,13 +13,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPSAT_LIB") or os.path.join(_HERE, "csrc", "libgpsat_hip.so")
 
 # constants mirrored from include/gpsat_hip.h
-ABI_VERSION = 2
+ABI_VERSION = 3
 F32, F64 = 0, 1
 KERNEL_IDS = {"RBF": 0, "SquaredExponential": 0, "Matern12": 1, "Exponential": 1, "Matern32": 2, "Matern52": 3}
 OPT_NONE, OPT_LBFGS, OPT_ADAM = 0, 1, 2
 OPT_IDS = {"none": OPT_NONE, None: OPT_NONE, "lbfgs": OPT_LBFGS, "L-BFGS-B": OPT_LBFGS, "adam": OPT_ADAM}
 MEM_HOST, MEM_DEVICE = 0, 1
-STATUS = {0: "converged", 1: "max_iter", 2: "not_pd", 3: "nan", 4: "skipped", 5: "not_optimised"}
+STATUS = {0: "converged", 1: "max_iter", 2: "not_pd", 3: "nan", 4: "skipped", 5: "not_optimised", 6: "ls_failed"}
 
 EXPORTS = ["gpsat_version", "gpsat_last_error", "gpsat_device_count", "gpsat_create", "gpsat_device_name",
            "gpsat_destroy", "gpsat_fit_predict_batch", "gpsat_last_timing", "gpsat_select_batch",
@@ -40,7 +40,7 @@ class GpsatBatch(C.Structure):
         ("X", C.c_void_p), ("y", C.c_void_p), ("Xs", C.c_void_p),
         ("theta", C.c_void_p), ("nll", C.c_void_p), ("grad", C.c_void_p), ("status", C.c_void_p),
         ("n_eval", C.c_void_p), ("f_mean", C.c_void_p), ("f_var", C.c_void_p), ("y_var", C.c_void_p),
-        ("cov_off", C.c_void_p), ("f_cov", C.c_void_p),
+        ("cov_off", C.c_void_p), ("f_cov", C.c_void_p), ("n_iter", C.c_void_p),
     ]
 
 

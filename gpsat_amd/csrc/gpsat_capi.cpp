@@ -193,7 +193,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     if ((rc = h->meta_f64.reserve(n_f64 * sizeof(double)))) return rc;
     if ((rc = h->meta_misc.reserve((size_t)T * sizeof(int) + 64 + 16))) return rc;
     if ((rc = h->out_f64.reserve(((size_t)T * H * 2 + (size_t)T) * sizeof(double)))) return rc;
-    if ((rc = h->out_i32.reserve((size_t)T * 2 * sizeof(int)))) return rc;
+    if ((rc = h->out_i32.reserve((size_t)T * 3 * sizeof(int)))) return rc;
     // fp32: two 4-wave workgroups per CU while a workgroup's LDS fits twice; beyond that one 8-wave workgroup per CU
     // (the 8-wave build of the same kernels), so that every SIMD still has two waves to overlap
     const bool w8 = !f64 && (gpsat::shared_bytes(D, NBmax) > 80 * 1024 || h->wg_per_cu == 1);
@@ -249,10 +249,11 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
 
     gpsat::KernelArgs a;
     a.T = T; a.kernel = b->kernel; a.optimiser = b->optimiser; a.max_iter = b->max_iter;
-    a.max_ls = b->max_ls > 0 ? b->max_ls : (f64 ? 20 : 10);
+    a.max_ls = b->max_ls > 0 ? b->max_ls : 20;                                 // SciPy L-BFGS-B maxls
     a.NBmax = NBmax;
-    a.ftol = b->ftol > 0 ? b->ftol : (f64 ? 2.220446049250313e-9 : 1e-6);   // SciPy factr*eps in fp64
-    a.gtol = b->gtol > 0 ? b->gtol : 1e-5;
+    // 0 = default (fp64: SciPy's factr*eps; fp32: its analogue above the fp32 noise floor); negative = criterion off
+    a.ftol = b->ftol > 0 ? b->ftol : (b->ftol < 0 ? -1.0 : (f64 ? 2.220446049250313e-9 : 1e-6));
+    a.gtol = b->gtol > 0 ? b->gtol : (b->gtol < 0 ? -1.0 : 1e-5);
     a.adam_lr = b->adam_lr > 0 ? b->adam_lr : 0.1;
     a.obs_off = d_i64; a.pred_off = d_i64 + (T + 1);
     a.theta0 = d_f64; a.lo = d_f64 + (size_t)T * H; a.hi = d_f64 + 2 * (size_t)T * H;
@@ -262,7 +263,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     a.theta = d_out; a.nll = d_out + (size_t)T * H;
     a.grad = b->grad ? d_out + (size_t)T * H + T : nullptr;
     int* d_oi = static_cast<int*>(h->out_i32.p);
-    a.status = d_oi; a.n_eval = d_oi + T;
+    a.status = d_oi; a.n_eval = d_oi + T; a.n_iter = d_oi + 2 * (size_t)T;
     a.f_mean = reinterpret_cast<float*>(dfm); a.f_var = reinterpret_cast<float*>(dfv); a.y_var = reinterpret_cast<float*>(dyv);
     a.order = d_order; a.queue = d_queue;
     a.ws = static_cast<float*>(h->ws.p); a.ws_stride = wsf;     // fp64: the kernel reinterprets ws as doubles
@@ -286,6 +287,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     if (b->grad) HIP_TRY(hipMemcpyAsync(b->grad, a.grad, (size_t)T * H * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(b->status, a.status, (size_t)T * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(b->n_eval, a.n_eval, (size_t)T * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (b->n_iter) HIP_TRY(hipMemcpyAsync(b->n_iter, a.n_iter, (size_t)T * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (b->memory == GPSAT_MEM_HOST && sumP > 0) {
         HIP_TRY(hipMemcpyAsync(b->f_mean, dfm, (size_t)sumP * esz, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipMemcpyAsync(b->f_var, dfv, (size_t)sumP * esz, hipMemcpyDeviceToHost, h->stream));

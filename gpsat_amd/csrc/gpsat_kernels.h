@@ -24,6 +24,7 @@ struct KernelArgs {
     double* grad;                 // [T*H] or nullptr
     int* status;                  // [T]
     int* n_eval;                  // [T]
+    int* n_iter;                  // [T] optimiser iterations completed, or nullptr
     float* f_mean;                // [sumP]
     float* f_var;
     float* y_var;

@@ -1145,6 +1145,7 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
         if (c.N == 0) {
             if (c.tid == 0) {
                 A.status[t] = 4; A.n_eval[t] = 0; A.nll[t] = 0.0;
+                if (A.n_iter) A.n_iter[t] = 0;
                 for (int i = 0; i < H; ++i) {
                     A.theta[(size_t)t * H + i] = A.theta0[(size_t)t * H + i];
                     if (A.grad) A.grad[(size_t)t * H + i] = 0.0;
@@ -1219,6 +1220,7 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
             if (sh->fail) st = (sh->nll == sh->nll) ? 2 : 3;
             A.status[t] = st;
             A.n_eval[t] = sh->n_eval_opt;
+            if (A.n_iter) A.n_iter[t] = sh->iter;
             A.nll[t] = sh->fail ? __builtin_nan("") : sh->nll;
             for (int i = 0; i < H; ++i) {
                 A.theta[(size_t)t * H + i] = sh->theta[i];

@@ -9,7 +9,7 @@
 constexpr int NW = GPSAT_NW;   // waves per workgroup (power of two; fp32 kernels 4, fp64 kernels see gpsat_kernels_f64.hip)
 constexpr int NT = 64 * NW;    // threads per workgroup
 constexpr int HMAX = 6;        // max D + 2 (D <= 4)
-constexpr int MH = 8;          // L-BFGS history
+constexpr int MH = 10;         // L-BFGS history (SciPy L-BFGS-B maxcor default)
 
 // ---------------------------------------------------------------------------------------------
 // per-workgroup state
@@ -25,6 +25,7 @@ struct Shared {
     double lo[HMAX], hi[HMAX], shift[HMAX];
     double u[HMAX], g[HMAX], f;            // current accepted point (u-space)
     double ut[HMAX], gt[HMAX], ft;         // trial point
+    double ub[HMAX], gb[HMAX];             // best sufficient-decrease point of the running line search (value f_best)
     double d[HMAX];
     double S[MH][HMAX], Y[MH][HMAX], rho_[MH];
     double m1[HMAX], m2[HMAX];             // Adam moments
@@ -141,7 +142,10 @@ static __device__ __noinline__ void ls_step(Shared* sh, int H, int max_ls) {
     for (int i = 0; i < H; ++i) dphit += sh->gt[i] * sh->d[i];
     const bool finite = (ft == ft) && (ft < 1e300);
     const bool armijo = finite && (ft <= sh->f + c1 * t * sh->dphi0);
-    if (armijo && ft < sh->f_best) { sh->f_best = ft; sh->t_best = t; }
+    if (armijo && ft < sh->f_best) {
+        sh->f_best = ft; sh->t_best = t;
+        for (int i = 0; i < H; ++i) { sh->ub[i] = sh->ut[i]; sh->gb[i] = sh->gt[i]; }
+    }
     sh->ls_iter += 1;
     if (armijo && fabs(dphit) <= -c2 * sh->dphi0) { sh->ls_done = 1; return; }
     if (sh->ls_iter >= max_ls) { sh->ls_done = (armijo ? 1 : 2); return; }
@@ -191,6 +195,9 @@ static __device__ __noinline__ void ls_step(Shared* sh, int H, int max_ls) {
 // optimiser driver (thread 0): a state machine advanced once per objective evaluation, so that the
 // kernel has ONE inlined call site of evaluate().
 // ---------------------------------------------------------------------------------------------
+// per-tile status codes written by the optimiser (include/gpsat_hip.h GPSAT_STATUS_*)
+enum { ST_CONVERGED = 0, ST_MAXITER = 1, ST_LS_FAILED = 6 };
+
 enum { PH_INIT = 0, PH_LS = 1, PH_ADAM = 2, PH_FINAL = 3, PH_EXIT = 4 };
 
 struct OptCfg { int optimiser, max_iter, max_ls, want_grad_out; double ftol, gtol, adam_lr; };
@@ -248,6 +255,12 @@ static __device__ __noinline__ void opt_advance(Shared* sh, int H, const OptCfg&
             for (int i = 0; i < H; ++i) sh->g[i] = sh->gt[i];
             if (sh->fail) { sh->status = 2; sh->n_eval_opt = sh->n_eval; sh->phase = PH_EXIT; return; }
             sh->status = 1;
+            if (o.optimiser == 1 && o.gtol > 0.0) {
+                // L-BFGS-B tests the gradient norm before the first iteration too
+                double gmax0 = 0.0;
+                for (int i = 0; i < H; ++i) gmax0 = fmax(gmax0, fabs(sh->g[i]));
+                if (gmax0 <= o.gtol) { sh->status = 0; opt_finish(sh, H, o, true); return; }
+            }
             opt_start_iteration(sh, H, o);
             return;
         }
@@ -298,15 +311,22 @@ static __device__ __noinline__ void opt_advance(Shared* sh, int H, const OptCfg&
                 opt_start_iteration(sh, H, o);
                 return;
             }
-            // line search failed: no further decrease is resolvable at this precision.  Restart from steepest
-            // descent only when the last accepted step still made real progress (far from the noise floor).
-            if (sh->hist_n > 0 && sh->iter + 1 < o.max_iter && sh->last_dec > 1e3 * o.ftol * fmax(fabs(sh->f), 1.0)) {
-                sh->hist_n = 0;           // one restart with steepest descent from the accepted point
-                sh->iter += 1;
+            // Line search failed (no step satisfying the strong Wolfe conditions within max_ls evaluations).  As L-BFGS-B
+            // does (lnsrlb info != 0): with a non-empty history, discard it and restart once from steepest descent at the
+            // accepted point (the restart is not an iteration); with an empty history give up -- SciPy reports
+            // ABNORMAL_TERMINATION_IN_LNSRCH, success=False, hence a status of its own.  The best sufficient-decrease
+            // point seen by the failed search (if any) is kept rather than thrown away.
+            if (sh->hist_n > 0) {
+                sh->hist_n = 0;
                 opt_start_iteration(sh, H, o);
                 return;
             }
-            sh->status = (sh->iter + 1 >= o.max_iter && sh->hist_n > 0) ? 1 : 0;
+            sh->status = ST_LS_FAILED;
+            if (sh->t_best > 0.0 && sh->f_best < sh->f) {
+                sh->last_dec = sh->f - sh->f_best;
+                sh->f = sh->f_best;
+                for (int i = 0; i < H; ++i) { sh->u[i] = sh->ub[i]; sh->g[i] = sh->gb[i]; }
+            }
             opt_finish(sh, H, o, false);
             return;
         }

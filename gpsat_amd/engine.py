@@ -30,8 +30,24 @@ class BatchResult:
     grad: np.ndarray | None = None   # [T, H] dNLL/dtheta at theta (when requested)
     f_cov: object = None   # full_cov: flat [sum P_t^2] (numpy / torch as f_mean); tile t = f_cov[cov_off[t]:cov_off[t+1]].reshape(P_t, P_t)
     cov_off: np.ndarray | None = None
+    n_iter: np.ndarray | None = None   # [T] optimiser iterations completed (scipy nit)
     kernel_ms: float = 0.0
     total_ms: float = 0.0
+
+
+def centre_tiles(X, Xs, obs_off, pred_off):
+    """Subtract every tile's mean coordinate from its observations and prediction points (fp64).
+
+    The covariance functions are stationary, so the model is unchanged; what changes is the rounding of the cast to
+    fp32 that follows: GPSat coordinates are typically far from the origin (t ~ 18 000 days against length scales of a
+    few days), where fp32 resolves the scaled coordinate to ~1e-3 only.  Centred, the cast error is relative to the
+    tile's own extent."""
+    Ns, Ps = np.diff(obs_off), np.diff(pred_off)
+    nz = Ns > 0
+    c = np.zeros((len(Ns), X.shape[1]))
+    if nz.any():
+        c[nz] = np.add.reduceat(X, obs_off[:-1][nz], axis=0) / Ns[nz, None]
+    return X - np.repeat(c, Ns, axis=0), Xs - np.repeat(c, Ps, axis=0)
 
 
 def _ptr(a):
@@ -116,6 +132,10 @@ class Engine:
             pX, py, pXs = X.data_ptr(), y.data_ptr(), Xs.data_ptr()
             pfm, pfv, pyv = fm.data_ptr(), fv.data_ptr(), yv.data_ptr()
         else:
+            if dtype == "f32" and sumN > 0 and np.asarray(X).dtype == np.float64:
+                # fp64 coordinates handed to the fp32 kernels: centre per tile before the cast (see centre_tiles)
+                X, Xs = centre_tiles(np.asarray(X, dtype=np.float64).reshape(sumN, D),
+                                     np.asarray(Xs, dtype=np.float64).reshape(sumP, D), obs_off, pred_off)
             X = np.ascontiguousarray(X, dtype=np_dt).reshape(sumN, D)
             y = np.ascontiguousarray(y, dtype=np_dt).reshape(sumN)
             Xs = np.ascontiguousarray(Xs, dtype=np_dt).reshape(sumP, D)
@@ -140,6 +160,7 @@ class Engine:
         grad = np.empty((T, H), dtype=np.float64) if want_grad else None
         status = np.empty(T, dtype=np.int32)
         n_eval = np.empty(T, dtype=np.int32)
+        n_iter = np.zeros(T, dtype=np.int32)
 
         b = L.GpsatBatch()
         b.T, b.D, b.dtype = T, D, (L.F32 if dtype == "f32" else L.F64)
@@ -152,7 +173,7 @@ class Engine:
         b.theta0, b.lo, b.hi, b.trainable = _ptr(theta0), _ptr(lo), _ptr(hi), _ptr(trainable)
         b.X, b.y, b.Xs = pX, py, pXs
         b.theta, b.nll, b.grad = _ptr(theta), _ptr(nll), _ptr(grad)
-        b.status, b.n_eval = _ptr(status), _ptr(n_eval)
+        b.status, b.n_eval, b.n_iter = _ptr(status), _ptr(n_eval), _ptr(n_iter)
         b.f_mean, b.f_var, b.y_var = pfm, pfv, pyv
         b.cov_off, b.f_cov = (_ptr(cov_off), pfc) if full_cov else (None, None)
         rc = self._lib.gpsat_fit_predict_batch(self._h, C.byref(b))
@@ -162,7 +183,7 @@ class Engine:
         self._lib.gpsat_last_timing(self._h, C.byref(km), C.byref(tm))
         if device_mode:
             fm, fv, yv = fm[:sumP], fv[:sumP], yv[:sumP]
-        return BatchResult(theta=theta, nll=nll, status=status, n_eval=n_eval, f_mean=fm, f_var=fv, y_var=yv,
+        return BatchResult(theta=theta, nll=nll, status=status, n_eval=n_eval, n_iter=n_iter, f_mean=fm, f_var=fv, y_var=yv,
                            grad=grad, kernel_ms=km.value, total_ms=tm.value,
                            f_cov=(fc[:int(cov_off[-1])] if full_cov else None), cov_off=cov_off)
 

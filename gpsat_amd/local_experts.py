@@ -4,36 +4,52 @@ Reference: ``LocalExpertOI.run`` (GPSat/local_experts.py:761-1279) loops seriall
 tile, selects observations (``DataLoader.local_data_select``, GPSat/dataloader.py:2352-2447), builds the
 prediction coordinates (``PredictionLocations``, GPSat/prediction_locations.py:18-43,72-115,208-281), constructs a
 model, applies constraints, optimises, evaluates the objective, predicts and appends rows to result tables
-(``dict_of_array_to_table``, GPSat/local_experts.py:691-747).
+(``dict_of_array_to_table``, GPSat/local_experts.py:691-747) every ``store_every`` tiles (:500-548).
 
-Here the SAME four config dicts are accepted (the in-memory subset listed below), selection is done for ALL
-expert locations first (fp64 on the host, the reference's comparison semantics: ``ref + val`` offsets, inclusive
-radius for observations, strict ``<`` for prediction locations, source row order preserved), the tiles are packed
-into one ragged batch and fitted + predicted by ONE ``gpsat_fit_predict_batch`` call per wave, and the reference's
-tables (``run_details``, ``preds``, ``lengthscales``, ``kernel_variance``, ``likelihood_variance``, ``expert_locs``,
-``oi_config``; columns ``_dim_0``, ``f*``, ``f*_var``, ``y_var``, ``f_bar``, ``pred_loc_<c>`` ...) are produced with the
-expert coordinates as (Multi)Index.  The store is a directory of pandas-pickled tables (pytables/HDF5 is not a dependency
-of this backend); re-running skips expert locations already present in ``run_details`` (resume,
-local_experts.py:475-497,908-912).
+Here the SAME four config dicts are accepted (the in-memory subset listed below).  The work is organised as
+
+  pass 1  tile membership for ALL expert locations (fp64, the reference's comparison semantics: ``ref + val``
+          offsets, inclusive radius for observations, strict ``<`` for prediction locations, source row order;
+          one GPU call with ``device_select=True``), scaling / de-meaning and the per-tile parameter vectors
+          (defaults, loaded parameters, box constraints with move-within-tol) as whole-array operations -- no per-tile
+          model object, no per-tile DataFrame;
+  shard   with ``world_size > 1`` the global tile list is split by ``sharding.partition_tiles`` (LPT on
+          E*N^3 + N^2*P); every rank packs and runs only its own tiles; no data-path collective;
+  pass 2  waves of ``store_every`` expert locations: one ``gpsat_fit_predict_batch`` call per wave (and per model
+          profile), tables assembled with array operations and flushed to the store as one append-only, atomically
+          committed part per wave -- a fault at tile 99 999 loses at most the running wave, and a re-run resumes
+          after the last committed wave (the reference's resume contract, local_experts.py:475-497,908-912);
+  gather  with ``world_size > 1`` ONE gather (``sharding.gather_results``: RCCL over xGMI on the GPU node) returns
+          per-tile hyper-parameters + predictions to rank 0, which assembles the tables in the reference's expert order.
+
+Tables (``run_details``, ``preds``, ``lengthscales``, ``kernel_variance``, ``likelihood_variance``, ``expert_locs``,
+``oi_config``; columns ``_dim_0``, ``f*``, ``f*_var``, ``y_var``, ``f_bar``, ``pred_loc_<c>`` ...) carry the expert
+coordinates as (Multi)Index like the reference's.  The store is a directory of pandas-pickled parts (pytables / HDF5
+is not a dependency of this backend).
 
 Supported config subset (anything else raises ``NotImplementedError`` -- never a silent fallback):
   expert_loc_config : {"source": DataFrame | csv/parquet path, "sort_by": optional col(s)}
   data_config       : {"data_source": DataFrame | path, "obs_col": str, "coords_col": [..],
                        "local_select": [{"col", "comp", "val"}, ...], "global_select": [static {"col","comp","val"}]}
   pred_loc_config   : {"method": "expert_loc"} | {"method": "from_dataframe", "df": DataFrame, "max_dist": float,
-                       "local_select": optional}
+                       "local_select": optional} | {"method": "from_source", "load_kwargs": {"source": DataFrame | path},
+                       "max_dist": ..} | {"method": "shift_arrays", "<coord>": array, ...}
   model_config      : {"oi_model": "HipGPRModel" | "GPflowGPRModel" | {"path_to_model", "model_name"},
                        "init_params", "constraints", "optim_kwargs", "pred_kwargs", "params_to_store",
-                       "load_params": {"file": store dir | dict of tables, "table_suffix": str}}
+                       "load_params": {"file": store dir | dict of tables, "table_suffix": str, "param_names": [..],
+                                       "index_adjust": {col: {"func": callable | "lambda ..."}}} |
+                                      {<param>: value, ...}  (set directly on every tile)}
 ``replacement_*`` model settings for tiles below ``replacement_threshold`` observations are honoured (one engine call
-per model profile).  ``load_params.previous=True`` (an exponential moving average of earlier tiles' optima, a serial cross-tile
-dependency, local_experts.py:1200-1217) is rejected explicitly.
+per model profile and wave).  ``load_params.previous=True`` (an exponential moving average of earlier tiles' optima, a
+serial cross-tile dependency, local_experts.py:1200-1217) is rejected explicitly.
 """
 from __future__ import annotations
 
 import json
 import os
+import re
 import time
+import warnings
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -41,10 +57,14 @@ import pandas as pd
 from scipy.spatial import cKDTree
 
 from . import _lib as L
-from .models import HipGPRModel, LIKELIHOOD_VARIANCE_LOWER_BOUND
+from . import sharding
+from .models import HipGPRModel, LIKELIHOOD_VARIANCE_LOWER_BOUND, clamp_within
 
 _COMPS = {">=": np.greater_equal, ">": np.greater, "==": np.equal, "<": np.less, "<=": np.less_equal}
 PARAM_NAMES = ["lengthscales", "kernel_variance", "likelihood_variance"]
+MODEL_NAME = f"{HipGPRModel.__module__}.{HipGPRModel.__name__}"[:64]
+# largest tile the kernels take (gpsat_capi.cpp); larger tiles get an explicit error row instead of failing the batch
+MAX_OBS = {"f32": 4096, "f64": 2560}
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -84,11 +104,13 @@ class LocalSelector:
         self.df = df
         self.local_select = local_select or []
         self._trees = {}
+        self._cols = {}
         for idx, ls in enumerate(self.local_select):
             col, comp = ls["col"], ls["comp"]
             if isinstance(col, str):
                 assert col in df, f"col: {col} is not in data - {df.columns}"
                 assert comp in _COMPS, f"comp: {comp} is not valid"
+                self._cols[col] = df[col].values
             else:
                 assert comp in ["<", "<="], "for multi dimensional values only less than comparison handled"
                 for c_ in col:
@@ -101,7 +123,7 @@ class LocalSelector:
             col, comp = ls["col"], ls["comp"]
             if isinstance(col, str):
                 assert col in ref, f"col: {col} is not in reference_location - {ref.keys()}"
-                select &= _COMPS[comp](self.df[col].values, ref[col] + ls["val"])
+                select &= _COMPS[comp](self._cols[col], ref[col] + ls["val"])
             else:
                 for c_ in col:
                     assert c_ in ref, f"col: {col} is not in reference_location - {ref.keys()}"
@@ -110,6 +132,17 @@ class LocalSelector:
                 m[ids] = True
                 select &= m
         return select
+
+    def select(self, refs: pd.DataFrame):
+        """CSR (off [T+1], idx) of selected row POSITIONS for every row of ``refs`` (same layout as DeviceSelector)."""
+        cols = list(refs.columns)
+        vals = refs.values
+        chunks, off = [], np.zeros(len(refs) + 1, dtype=np.int64)
+        for i in range(len(refs)):
+            ids = np.nonzero(self.mask(dict(zip(cols, vals[i]))))[0]
+            chunks.append(ids)
+            off[i + 1] = off[i] + len(ids)
+        return off, (np.concatenate(chunks) if chunks else np.zeros(0, np.int64)).astype(np.int64)
 
 
 class DeviceSelector:
@@ -159,42 +192,86 @@ def max_dist_bool(loc: np.ndarray, ref_loc: np.ndarray, max_dist: float) -> np.n
 
 
 class PredictionLocations:
-    """Prediction coordinates per expert (GPSat/prediction_locations.py:72-115,208-281): ``expert_loc`` or
-    ``from_dataframe`` with ``max_dist`` over the columns present in the frame; dimensions missing from the frame
-    are filled from the expert location (:262-271); optional ``local_select`` afterwards (:106-111)."""
+    """Prediction coordinates per expert (GPSat/prediction_locations.py:72-115,182-281):
 
-    def __init__(self, method="expert_loc", coords_col=None, df=None, max_dist=None, local_select=None, **kw):
-        if method not in ("expert_loc", "from_dataframe"):
-            raise NotImplementedError(f"prediction location method '{method}' is not built (expert_loc, from_dataframe)")
-        if kw:
+    ``expert_loc``      the expert location itself;
+    ``shift_arrays``    the mesh of per-coordinate shift arrays (``<coord>=array`` keywords, missing coordinates shift
+                        by 0; built once, :182-206) added to the expert location;
+    ``from_dataframe``  rows of a frame within ``max_dist`` (strict) over the columns present in the frame; dimensions
+                        missing from the frame are filled from the expert location (:262-271); optional
+                        ``local_select`` afterwards (:106-111);
+    ``from_source``     ``load_kwargs={"source": DataFrame | csv | parquet}`` loaded once, duplicates dropped, then as
+                        ``from_dataframe`` (:83-101)."""
+
+    def __init__(self, method="expert_loc", coords_col=None, df=None, max_dist=None, local_select=None,
+                 load_kwargs=None, Xout=None, **kw):
+        self.coords_col = list(coords_col)
+        if method == "from_source":
+            assert load_kwargs is not None, \
+                "calling PredictionLocations object with method='from_source', however 'load_kwargs' is missing"
+            extra = set(load_kwargs) - {"source"}
+            if extra:
+                raise NotImplementedError(f"from_source load_kwargs {sorted(extra)}: only 'source' is supported")
+            df = _load_frame(load_kwargs["source"]).drop_duplicates()
+            method = "from_dataframe"
+        if method not in ("expert_loc", "from_dataframe", "shift_arrays"):
+            raise ValueError(f"prediction location method '{method}' is not implemented")
+        self.method, self.max_dist, self.local_select = method, max_dist, local_select
+        if method == "shift_arrays":
+            unknown = set(kw) - set(self.coords_col)
+            if unknown:
+                raise NotImplementedError(f"shift_arrays: {sorted(unknown)} are not coordinate columns")
+            if Xout is None:
+                axes = [np.atleast_1d(np.asarray(kw.get(c, np.zeros(1)), dtype=np.float64)) for c in self.coords_col]
+                for a in axes:
+                    assert a.ndim == 1
+                mesh = np.meshgrid(*axes, indexing="ij")
+                Xout = np.stack([m.reshape(-1) for m in mesh], axis=1)
+            self.shifts = np.asarray(Xout, dtype=np.float64)
+            assert self.shifts.ndim == 2 and self.shifts.shape[1] == len(self.coords_col)
+        elif kw:
             raise NotImplementedError(f"unsupported pred_loc_config keys: {sorted(kw)}")
-        self.method, self.coords_col, self.max_dist, self.local_select = method, list(coords_col), max_dist, local_select
         if method == "from_dataframe":
             df = _load_frame(df)
             self.found = [c for c in self.coords_col if c in df.columns]
             self.fc_loc = [self.coords_col.index(c) for c in self.found]
             self.vals = df.loc[:, self.found].values.astype(np.float64)
-            if local_select:
-                self._frame = pd.DataFrame(self.vals, columns=self.found)
+            self.missing = [i for i, c in enumerate(self.coords_col) if c not in self.found]
+            self._sel = LocalSelector(pd.DataFrame(self.vals, columns=self.found), local_select) if local_select else None
 
     def __call__(self, expert_loc: np.ndarray) -> np.ndarray:
         """expert_loc: (D,) fp64 in the order of coords_col.  Returns (P, D) fp64."""
         if self.method == "expert_loc":
             return expert_loc[None, :].copy()
+        if self.method == "shift_arrays":
+            return self.shifts + expert_loc[None, :]
         b = max_dist_bool(self.vals, expert_loc[self.fc_loc], self.max_dist) if self.max_dist is not None \
             else np.ones(len(self.vals), dtype=bool)
-        if self.local_select:
-            ref = {c: expert_loc[i] for i, c in enumerate(self.coords_col)}
-            b = b & LocalSelector(self._frame, self.local_select).mask(ref)
-        out = np.full((int(b.sum()), len(self.coords_col)), np.nan)
-        out[:, self.fc_loc] = self.vals[b]
-        missing = [i for i, c in enumerate(self.coords_col) if c not in self.found]
-        out[:, missing] = expert_loc[missing]
+        if self._sel is not None:
+            b = b & self._sel.mask({c: expert_loc[i] for i, c in enumerate(self.coords_col)})
+        return self._rows(np.nonzero(b)[0], expert_loc)
+
+    def _rows(self, ids, expert_loc):
+        out = np.empty((len(ids), len(self.coords_col)))
+        out[:, self.fc_loc] = self.vals[ids]
+        out[:, self.missing] = expert_loc[self.missing]
         return out
+
+    def batch(self, locs: np.ndarray, engine=None):
+        """All experts at once: (list of (P_i, D) arrays).  With an engine the ``max_dist`` filter of ``from_dataframe``
+        runs as ONE ``gpsat_select_batch`` call (strict ball, bit-identical membership)."""
+        if self.method == "from_dataframe" and engine is not None and self.max_dist is not None and self._sel is None \
+                and 1 <= len(self.found) <= 3:
+            frame = pd.DataFrame(self.vals, columns=self.found)
+            ds = DeviceSelector(frame, [{"col": list(self.found), "comp": "<", "val": self.max_dist}], engine,
+                                strict_ball=True)
+            off, idx = ds.select(pd.DataFrame(locs[:, self.fc_loc], columns=self.found))
+            return [self._rows(idx[off[i]:off[i + 1]], locs[i]) for i in range(len(locs))]
+        return [self(locs[i]) for i in range(len(locs))]
 
 
 # ----------------------------------------------------------------------------------------------------------
-# result tables (GPSat/local_experts.py:691-747, GPSat/utils.py:1437-1495)
+# result tables (GPSat/local_experts.py:691-747, GPSat/utils.py:1437-1495) and their store
 # ----------------------------------------------------------------------------------------------------------
 def _index_for(coords_col, loc_rows: np.ndarray):
     if len(coords_col) == 1:
@@ -202,43 +279,144 @@ def _index_for(coords_col, loc_rows: np.ndarray):
     return pd.MultiIndex.from_arrays([loc_rows[:, i] for i in range(loc_rows.shape[1])], names=coords_col)
 
 
-class ResultStore:
-    """Directory of pandas-pickled tables named ``<table><suffix>.pkl`` (+ ``oi_config<suffix>.json``): no
-    dependency beyond pandas itself (pytables / pyarrow are not guaranteed on the GPU hosts)."""
+_PART_RE = re.compile(r"^(?P<table>.+)\.w(?P<k>\d{6})\.r(?P<r>\d{3})\.pkl$")
+_MARK_RE = re.compile(r"^_wave\.w(?P<k>\d{6})\.r(?P<r>\d{3})\.ok$")
 
-    def __init__(self, path: Optional[str]):
+
+class ResultStore:
+    """Directory store of pandas-pickled tables (no dependency beyond pandas itself; pytables / pyarrow are not
+    guaranteed on the GPU hosts).
+
+    Append-only: every flush (``write_wave``) adds ONE new part file per table, ``<table>.w<k>.r<rank>.pkl``, and
+    commits the wave by writing the marker ``_wave.w<k>.r<rank>.ok`` last (files are written to a temporary name and
+    renamed, so a part is either complete or absent).  Parts without their marker -- a run killed mid-flush -- are
+    ignored by readers and removed by the next run.  Nothing already written is ever re-read or re-written by an
+    append (the reference's HDFStore.append, local_experts.py:526-548).  ``put`` writes a whole table
+    (``<table>.pkl``, the HDFStore.put(append=False) of the smoothing step)."""
+
+    def __init__(self, path: Optional[str], rank: int = 0):
         self.path = path
+        self.rank = int(rank)
         if path:
             os.makedirs(path, exist_ok=True)
 
     def _file(self, table):
         return os.path.join(self.path, f"{table}.pkl")
 
-    def read(self, table) -> Optional[pd.DataFrame]:
-        if not self.path or not os.path.exists(self._file(table)):
-            return None
-        return pd.read_pickle(self._file(table))
+    def _scan(self):
+        parts, marks = {}, set()
+        for f in os.listdir(self.path):
+            m = _MARK_RE.match(f)
+            if m:
+                marks.add((int(m["k"]), int(m["r"])))
+                continue
+            m = _PART_RE.match(f)
+            if m:
+                parts.setdefault(m["table"], []).append((int(m["k"]), int(m["r"]), f))
+        return parts, marks
+
+    def drop_uncommitted(self):
+        """Remove part files of this rank that no marker commits (left by a run that died during a flush)."""
+        if not self.path:
+            return
+        parts, marks = self._scan()
+        for plist in parts.values():
+            for k, r, f in plist:
+                if r == self.rank and (k, r) not in marks:
+                    os.remove(os.path.join(self.path, f))
+
+    def _atomic_pickle(self, df, name):
+        tmp = os.path.join(self.path, f".tmp.{os.getpid()}.{name}")
+        df.to_pickle(tmp)
+        os.replace(tmp, os.path.join(self.path, name))
+
+    def write_wave(self, tables: Dict[str, pd.DataFrame]):
+        """One committed part per non-empty table."""
+        if not self.path:
+            return
+        tables = {k: v for k, v in tables.items() if v is not None and len(v)}
+        if not tables:
+            return
+        _, marks = self._scan()
+        k = 1 + max([kk for kk, r in marks if r == self.rank], default=0)
+        for name, df in tables.items():
+            self._atomic_pickle(df, f"{name}.w{k:06d}.r{self.rank:03d}.pkl")
+        mark = os.path.join(self.path, f"_wave.w{k:06d}.r{self.rank:03d}.ok")
+        with open(mark + ".tmp", "w") as f:
+            f.write(json.dumps({"tables": sorted(tables), "rows": {n: int(len(d)) for n, d in tables.items()}}))
+        os.replace(mark + ".tmp", mark)
 
     def append(self, table, df: pd.DataFrame):
-        if not self.path or df is None or len(df) == 0:
+        self.write_wave({table: df})
+
+    def put(self, table, df: pd.DataFrame):
+        """Whole-table write: replaces the table and every part of it."""
+        if not self.path:
             return
-        old = self.read(table)
-        if old is not None:
-            df = pd.concat([old, df])
-        df.to_pickle(self._file(table))
+        parts, _ = self._scan()
+        for _, _, f in parts.get(table, []):
+            os.remove(os.path.join(self.path, f))
+        self._atomic_pickle(df, f"{table}.pkl")
+
+    def read(self, table) -> Optional[pd.DataFrame]:
+        if not self.path:
+            return None
+        parts, marks = self._scan()
+        pieces = []
+        if os.path.exists(self._file(table)):
+            pieces.append(pd.read_pickle(self._file(table)))
+        for k, r, f in sorted(parts.get(table, [])):
+            if (k, r) in marks:
+                pieces.append(pd.read_pickle(os.path.join(self.path, f)))
+        if not pieces:
+            return None
+        return pieces[0] if len(pieces) == 1 else pd.concat(pieces)
+
+    def table_names(self) -> List[str]:
+        if not self.path:
+            return []
+        parts, marks = self._scan()
+        names = {t for t, pl in parts.items() if any((k, r) in marks for k, r, _ in pl)}
+        names |= {f[:-4] for f in os.listdir(self.path) if f.endswith(".pkl") and not _PART_RE.match(f)
+                  and not f.startswith(".tmp.")}
+        return sorted(names)
 
     def tables(self) -> Dict[str, pd.DataFrame]:
-        out = {}
-        if self.path:
-            for f in sorted(os.listdir(self.path)):
-                if f.endswith(".pkl"):
-                    out[f[:-4]] = pd.read_pickle(os.path.join(self.path, f))
-        return out
+        return {t: self.read(t) for t in self.table_names()}
 
 
-def get_results(store_path: str) -> Dict[str, pd.DataFrame]:
-    """Counterpart of ``get_results_from_h5file`` (GPSat/local_experts.py:1467): all tables of a store."""
-    return ResultStore(store_path).tables()
+def get_results(store_path: str, expert_order: bool = False) -> Dict[str, pd.DataFrame]:
+    """Counterpart of ``get_results_from_h5file`` (GPSat/local_experts.py:1467): all tables of a store.  With
+    ``expert_order=True`` the rows of every table are put in the order of the ``expert_locs`` table (a sharded run
+    commits its parts in (wave, rank) order)."""
+    tabs = ResultStore(store_path).tables()
+    if expert_order:
+        xl = next((v for k, v in tabs.items() if k.startswith("expert_locs")), None)
+        if xl is not None:
+            for k, v in tabs.items():
+                if k.startswith("expert_locs") or v.index.names != xl.index.names or len(v) == 0:
+                    continue
+                pos = xl.index.get_indexer(v.index)
+                tabs[k] = v.iloc[np.argsort(pos, kind="stable")]
+    return tabs
+
+
+def check_prev_oi_config(prev_oi_config: dict, oi_config: dict, skip_valid_checks_on=None):
+    """What ``GPSat.utils.check_prev_oi_config`` (utils.py:1276-1327) is documented to do: raise when a key of the
+    current configuration, other than those in ``skip_valid_checks_on``, differs from the one a previous run stored
+    for the same tables.  (The reference's final ``assert len(bad_keys)`` tests the opposite of its docstring.)"""
+    skip = set(skip_valid_checks_on or [])
+    bad = [k for k, v in oi_config.items() if k not in skip and prev_oi_config.get(k) != v]
+    assert not bad, f"the following keys did not have values that matched exactly: {bad}"
+
+
+def _adjust_func(spec):
+    f = spec.get("func") if isinstance(spec, dict) else spec
+    if callable(f):
+        return f
+    if isinstance(f, str) and f.lstrip().startswith("lambda"):
+        return eval(f)                                     # the reference's config_func does the same (utils.py:311)
+    raise NotImplementedError("load_params.index_adjust takes {col: {'func': callable or 'lambda x: ...'}}")
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -246,9 +424,12 @@ def get_results(store_path: str) -> Dict[str, pd.DataFrame]:
 # ----------------------------------------------------------------------------------------------------------
 class BatchedLocalExpertOI:
     def __init__(self, expert_loc_config: dict, data_config: dict, model_config: dict, pred_loc_config: dict,
-                 engine=None, device_select: bool = False):
+                 engine=None, device_select: bool = False, dtype: str = "f32"):
         self.config = {"locations": _jsonable(expert_loc_config), "data": _jsonable(data_config),
                        "model": _jsonable(model_config), "pred_loc": _jsonable(pred_loc_config)}
+        if dtype not in MAX_OBS:
+            raise ValueError("dtype must be 'f32' (default) or 'f64' (the reference's precision)")
+        self.dtype = dtype
         # ---- data (local_experts.py:266-290)
         self.obs_col = data_config["obs_col"]
         self.coords_col = list(data_config["coords_col"])
@@ -309,173 +490,345 @@ class BatchedLocalExpertOI:
         self.engine = engine if engine is not None else default_engine()
         # tile membership for all experts in one GPU call (bit-identical to the host selector)
         self.device_select = device_select
+        self.timings = {}
 
-    # -- per-tile host-side model logic reuses the drop-in class (intake, scaling, defaults, constraints)
-    def _host_model(self, df_local, init_params=None):
-        return HipGPRModel(data=df_local, obs_col=self.obs_col, coords_col=self.coords_col, engine=self.engine,
-                           verbose=False, **(self.init_params if init_params is None else init_params))
+    # ------------------------------------------------------------------------------------------------------
+    # per-profile template: everything HipGPRModel's constructor + set_parameter_constraints decide that does not
+    # depend on the tile's rows (defaults, scales, box, trainable mask).  One throw-away model on a two-row frame,
+    # as the reference itself does to read param_names (postprocessing.py:202-211).
+    # ------------------------------------------------------------------------------------------------------
+    def _template(self, pf):
+        D = len(self.coords_col)
+        dummy = pd.DataFrame({**{c: [0.0, 1.0] for c in self.coords_col}, self.obs_col: [0.0, 1.0]})
+        m = HipGPRModel(data=dummy, obs_col=self.obs_col, coords_col=self.coords_col, engine=self.engine,
+                        verbose=False, dtype=self.dtype, **pf["init_params"])
+        theta_default = m._theta.copy()
+        cons = None
+        if pf["constraints"] is not None:
+            cons = {k: dict(v) for k, v in pf["constraints"].items()}
+            if pf["init_params"].get("coords_scale", None) is not None and "lengthscales" in cons:
+                cons["lengthscales"]["scale"] = True           # local_experts.py:1113-1114
+            m.set_parameter_constraints(cons, move_within_tol=True, tol=1e-2)
+        ok = pf["optim_kwargs"]
+        m._fix_hyperparameters(list(ok.get("fixed_params") or []))
+        # per constrained slice: the tolerance the clamp uses (gpflow_models.py:471-479 with run()'s tol = 1e-2)
+        clamp = []
+        for pn, c in (cons or {}).items():
+            sl = m._slice(pn)
+            if c.get("move_within_tol", True):
+                clamp.append((sl, float(c.get("tol", 1e-2))))
+        return dict(theta_default=theta_default, lo=m._lo.copy(), hi=m._hi.copy(), trainable=m._trainable.copy(),
+                    clamp=clamp, coords_scale=np.broadcast_to(m.coords_scale, (1, D)).astype(np.float64),
+                    obs_scale=float(m.obs_scale.reshape(-1)[0]),
+                    local_mean=isinstance(pf["init_params"].get("obs_mean"), str) and pf["init_params"]["obs_mean"] == "local",
+                    unconstrained_noise=not np.isfinite(m._lo[D + 1]), device=str(m.gpu_name)[:64])
 
-    def _loaded_params(self, store: ResultStore, suffix, ref_row, model):
-        """load_params from tables ``<param><suffix>`` where the index equals the expert coordinates
-        (local_experts.py:553-689).  Returns False when nothing usable was found (tile is skipped)."""
+    def _load_param_tables(self, store: "ResultStore", table_suffix):
+        """load_params tables, read ONCE per run and indexed by expert coordinates (local_experts.py:553-689)."""
         lp = self.load_params
         src = lp.get("file")
-        tsuf = lp.get("table_suffix", suffix)
-        found = False
-        for pn in lp.get("param_names", PARAM_NAMES):
-            tab = src.get(f"{pn}{tsuf}") if isinstance(src, dict) else ResultStore(src).read(f"{pn}{tsuf}")
-            if tab is None:
-                continue
-            key = tuple(ref_row[c] for c in self.coords_col)
-            try:
-                rows = tab.loc[[key if len(key) > 1 else key[0]]]
-            except KeyError:
-                continue
-            vals = rows.sort_values("_dim_0")[pn].values.astype(np.float64)
-            if len(vals) == 0 or np.isnan(vals).any():
-                continue                                   # NaN -> parameter dropped (local_experts.py:670-679)
-            model.set_parameters(**{pn: vals if pn == "lengthscales" else float(vals[0])})
-            found = True
-        return found
+        tsuf = lp.get("table_suffix", "")                  # load_params(table_suffix="") default, local_experts.py:561
+        names = lp.get("param_names") or PARAM_NAMES
+        out = {}
+        reader = None if isinstance(src, dict) else ResultStore(src)
+        for pn in names:
+            assert pn in PARAM_NAMES, f"provide param name:{pn}\nis not in param_names:{PARAM_NAMES}"
+            tab = src.get(f"{pn}{tsuf}") if isinstance(src, dict) else reader.read(f"{pn}{tsuf}")
+            if tab is not None and len(tab):
+                out[pn] = tab
+        return out
 
+    def _loaded_theta(self, tabs, locs, theta, unconstrained_noise):
+        """Overwrite rows of ``theta`` [T, H] with the stored parameters of each expert location.  Returns the mask of
+        tiles for which at least one parameter was found (the others are skipped, local_experts.py:1099-1101)."""
+        cc, D = self.coords_col, len(self.coords_col)
+        found_any = np.zeros(len(locs), dtype=bool)
+        look = locs.copy()
+        for col, spec in (self.load_params.get("index_adjust") or {}).items():
+            j = cc.index(col)
+            f = _adjust_func(spec)
+            look[:, j] = [f(v) for v in look[:, j]]
+        key = _index_for(cc, look)
+        slots = {"lengthscales": (0, D), "kernel_variance": (D, 1), "likelihood_variance": (D + 1, 1)}
+        for pn, tab in tabs.items():
+            start, width = slots[pn]
+            colvals = np.full((len(locs), width), np.nan)
+            for k in range(width):
+                sub = tab[tab["_dim_0"] == k] if "_dim_0" in tab.columns else tab
+                sub = sub[~sub.index.duplicated(keep="first")]
+                pos = sub.index.get_indexer(key)
+                col = sub[pn].values.astype(np.float64)
+                colvals[:, k] = np.where(pos >= 0, col[np.clip(pos, 0, max(len(col) - 1, 0))], np.nan) if len(col) else np.nan
+            good = ~np.isnan(colvals).any(axis=1)             # NaN -> parameter dropped (local_experts.py:670-679)
+            if pn == "likelihood_variance" and unconstrained_noise:
+                low = good & (colvals[:, 0] < LIKELIHOOD_VARIANCE_LOWER_BOUND)
+                if low.any():
+                    warnings.warn("likelihood_variance below variance_lower_bound: set to the bound (gpflow_models.py:404-409)")
+                colvals[low, 0] = LIKELIHOOD_VARIANCE_LOWER_BOUND
+            theta[good, start:start + width] = colvals[good]
+            found_any |= good
+        return found_any
+
+    # ------------------------------------------------------------------------------------------------------
     def run(self, store_path: Optional[str] = None, optimise: bool = True, predict: bool = True, min_obs: int = 3,
-            table_suffix: str = "", max_tiles_per_call: Optional[int] = None, check_config_compatible: bool = True):
+            table_suffix: str = "", max_tiles_per_call: Optional[int] = None, store_every: Optional[int] = None,
+            check_config_compatible: bool = True, skip_valid_checks_on: Optional[List[str]] = None,
+            rank: Optional[int] = None, world_size: Optional[int] = None, gather: bool = True):
+        """See the module docstring.  ``store_every``: expert locations per flushed wave (default 4096;
+        ``max_tiles_per_call`` is the older name of the same knob).  ``rank`` / ``world_size``: tile-sharded run, one
+        process per GPU (default: taken from an initialised ``torch.distributed`` group, else 0 / 1); with
+        ``gather=True`` rank 0 returns the global tables in expert order, the other ranks their own shard's."""
         t_start = time.perf_counter()
-        store = ResultStore(store_path)
+        if rank is None or world_size is None:
+            rank, world_size = _dist_rank_world()
+        store = ResultStore(store_path, rank=rank)
         cc = self.coords_col
+        D, H = len(cc), len(cc) + 2
         xl = self.expert_locs
-        # expert_locs table + config bookkeeping (local_experts.py:873-903)
+        wave_n = int(store_every or max_tiles_per_call or 4096)
+        # ---- expert_locs table + config bookkeeping (local_experts.py:873-903); rank 0 owns the shared files
+        config_id = 1
         if store_path:
+            store.drop_uncommitted()
             cfg_file = os.path.join(store_path, f"oi_config{table_suffix}.json")
             prev = json.load(open(cfg_file)) if os.path.exists(cfg_file) else []
-            prev.append({"idx": len(prev) + 1, "datetime": time.strftime("%Y-%m-%d %H:%M:%S"), "config": self.config})
-            json.dump(prev, open(cfg_file, "w"))
-            config_id = len(prev)
-            if store.read(f"expert_locs{table_suffix}") is None:
-                store.append(f"expert_locs{table_suffix}", xl.set_index(cc))
-        else:
-            config_id = 1
-        # resume: drop expert locations already in run_details (local_experts.py:475-497,908-912)
+            if prev and check_config_compatible:
+                check_prev_oi_config(prev[-1]["config"], self.config, skip_valid_checks_on)
+            config_id = len(prev) + 1
+            if rank == 0:
+                prev.append({"idx": config_id, "datetime": time.strftime("%Y-%m-%d %H:%M:%S"), "config": self.config,
+                             "run_kwargs": {"optimise": optimise, "predict": predict, "min_obs": min_obs,
+                                            "table_suffix": table_suffix, "store_every": wave_n, "dtype": self.dtype}})
+                with open(cfg_file + ".tmp", "w") as f:
+                    json.dump(prev, f)
+                os.replace(cfg_file + ".tmp", cfg_file)
+                if store.read(f"expert_locs{table_suffix}") is None:
+                    store.put(f"expert_locs{table_suffix}", xl.set_index(cc))
+        # ---- resume: drop expert locations already in run_details (local_experts.py:475-497,908-912)
         todo = np.ones(len(xl), dtype=bool)
         done = store.read(f"run_details{table_suffix}")
         if done is not None and len(done):
-            have = set(done.index.tolist())
-            keys = [tuple(r) if len(cc) > 1 else r[0] for r in xl[cc].values.tolist()]
-            todo = np.array([k not in have for k in keys])
-        selector = LocalSelector(self.df, self.local_select)
-        dev_off = dev_idx = None
-        if self.device_select and len(self.local_select):
-            dev_off, dev_idx = DeviceSelector(self.df, self.local_select, self.engine).select(xl)
-        D = len(cc)
-        # per profile (main / replacement): what one engine call needs to be uniform in
-        prof = {}
-        for pname, pf in self.profiles.items():
+            todo = ~np.asarray(_index_for(cc, xl[cc].values.astype(np.float64)).isin(done.index))
+        ex = np.nonzero(todo)[0]                                   # global expert positions still to run
+        locs = xl[cc].values.astype(np.float64)[ex]
+
+        # ---------------- pass 1: membership, prediction coordinates, parameter vectors (whole-array) ----------------
+        t0 = time.perf_counter()
+        refs = xl.iloc[ex]
+        if len(self.local_select):
+            sel = DeviceSelector(self.df, self.local_select, self.engine) if self.device_select \
+                else LocalSelector(self.df, self.local_select)
+            off, idx = sel.select(refs)
+        else:
+            off, idx = np.arange(len(ex) + 1, dtype=np.int64) * len(self.df), np.tile(np.arange(len(self.df)), len(ex))
+        n_obs = np.diff(off)
+        pcs = self.pred_loc.batch(locs, self.engine if self.device_select else None) if len(ex) else []
+        n_pred = np.array([len(p) for p in pcs], dtype=np.int64)
+        self.timings["select_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        # item kinds: 0 skipped silently (no prediction locations, local_experts.py:962-965), 1 stub row
+        # (N < min_obs, :988-1012), 2 tile, 3 error row (tile larger than the kernels take)
+        kind = np.full(len(ex), 2, dtype=np.int8)
+        kind[n_obs > MAX_OBS[self.dtype]] = 3
+        kind[n_obs < min_obs] = 1
+        kind[n_pred == 0] = 0
+        if (kind == 3).any():
+            warnings.warn(f"{int((kind == 3).sum())} expert locations select more than {MAX_OBS[self.dtype]} "
+                          f"observations: not run (error row in run_details)")
+        is_repl = (n_obs < self.replacement_threshold) if self.replacement_threshold is not None \
+            else np.zeros(len(ex), dtype=bool)                      # local_experts.py:1021-1041
+        prof_names = list(self.profiles)
+        prof_id = np.where(is_repl, prof_names.index("replacement") if "replacement" in prof_names else 0, 0)
+        tmpl, pinfo = {}, {}
+        for pi, pname in enumerate(prof_names):
+            pf = self.profiles[pname]
             kernel = pf["init_params"].get("kernel", "Matern32")
             if kernel not in L.KERNEL_IDS:
                 raise NotImplementedError(f"kernel {kernel!r}")
             ok = pf["optim_kwargs"]
-            prof[pname] = dict(kernel=kernel, fixed=list(ok.get("fixed_params") or []), max_iter=int(ok.get("max_iter", 10_000)),
-                               eng_kw={k: ok[k] for k in ("max_ls", "ftol", "gtol", "adam_lr") if k in ok},
-                               optimiser=ok.get("optimiser", "lbfgs") if optimise else "none", **pf)
+            tmpl[pi] = self._template(pf)
+            pinfo[pi] = dict(kernel=kernel, max_iter=int(ok.get("max_iter", 10_000)),
+                             eng_kw={k: ok[k] for k in ("max_ls", "ftol", "gtol", "adam_lr") if k in ok},
+                             optimiser=ok.get("optimiser", "lbfgs") if optimise else "none",
+                             apply_scale=pf["pred_kwargs"].get("apply_scale", True))
+        theta0 = np.zeros((len(ex), H))
+        lo = np.full((len(ex), H), np.nan)
+        hi = np.full((len(ex), H), np.nan)
+        save_params = np.ones(len(ex), dtype=bool)
+        for pi in tmpl:
+            m_ = prof_id == pi
+            theta0[m_], lo[m_], hi[m_] = tmpl[pi]["theta_default"], tmpl[pi]["lo"], tmpl[pi]["hi"]
+        if self.load_params is not None:
+            lp = self.load_params
+            if lp.get("file") is not None:
+                tabs = self._load_param_tables(store, table_suffix)
+                for pi in tmpl:
+                    m_ = np.nonzero((prof_id == pi) & (kind == 2))[0]
+                    th = theta0[m_]
+                    got = self._loaded_theta(tabs, locs[m_], th, tmpl[pi]["unconstrained_noise"])
+                    theta0[m_] = th
+                    kind[m_[~got]] = 0                              # nothing loadable: tile skipped (:1099-1101)
+                same = (lp.get("file") == store_path and lp.get("table_suffix", None) == table_suffix and
+                        set(lp) <= {"file", "table_suffix"})                  # _same_param_table, :749-758
+                save_params[:] = not (same and not optimise)        # local_experts.py:1090-1097
+            else:
+                # parameters given directly (load_params(**param_dict), local_experts.py:553-604)
+                direct = {k: v for k, v in lp.items() if k in PARAM_NAMES}
+                if not direct:
+                    raise NotImplementedError("load_params needs 'file' or parameter values")
+                for pn, v in direct.items():
+                    v = np.asarray(v, dtype=np.float64).reshape(-1)
+                    if pn == "lengthscales":
+                        theta0[:, :D] = v
+                    else:
+                        theta0[:, D + PARAM_NAMES.index(pn) - 1] = v[0]
+        for pi, t_ in tmpl.items():                                  # move within tol of the box (gpflow_models.py:471-479)
+            m_ = prof_id == pi
+            for sl, tol in t_["clamp"]:
+                theta0[m_, sl] = clamp_within(theta0[m_, sl], t_["lo"][sl], t_["hi"][sl], tol)
+        self.timings["params_s"] = time.perf_counter() - t0
 
-        # ---------------- pass 1: selection + host-side model logic for every expert (fp64) ----------------
-        tiles, stubs = [], []
-        for i in np.nonzero(todo)[0]:
-            rl = xl.iloc[i]
-            ref = {c: rl[c] for c in xl.columns}
-            loc = rl[cc].values.astype(np.float64)
-            pc = self.pred_loc(loc)
-            if len(pc) == 0:                                   # local_experts.py:962-965: skipped, nothing stored
-                continue
-            df_local = self.df.iloc[dev_idx[dev_off[i]:dev_off[i + 1]]] if dev_idx is not None \
-                else self.df.loc[selector.mask(ref)]
-            if len(df_local) < min_obs:                        # local_experts.py:988-1012: stub run_details row
-                stubs.append((loc, len(df_local)))
-                continue
-            pname = "replacement" if (self.replacement_threshold is not None and
-                                      len(df_local) < self.replacement_threshold) else "main"   # local_experts.py:1021-1041
-            pf = prof[pname]
-            m = self._host_model(df_local, pf["init_params"])
-            save_params = True
-            if self.load_params is not None:
-                if not self._loaded_params(store, table_suffix, ref, m):
-                    continue                                   # local_experts.py:1099-1101
-                same = (self.load_params.get("file") == store_path and
-                        self.load_params.get("table_suffix", table_suffix) == table_suffix and
-                        set(self.load_params) <= {"file", "table_suffix"})
-                save_params = not (same and not optimise)      # local_experts.py:1090-1097
-            if pf["constraints"] is not None:
-                cons = {k: dict(v) for k, v in pf["constraints"].items()}
-                if pf["init_params"].get("coords_scale", None) is not None and "lengthscales" in cons:
-                    cons["lengthscales"]["scale"] = True       # local_experts.py:1113-1114
-                m.set_parameter_constraints(cons, move_within_tol=True, tol=1e-2)
-            m._fix_hyperparameters(pf["fixed"])
-            pcs = pc / m.coords_scale if pf["pred_kwargs"].get("apply_scale", True) else pc
-            tiles.append(dict(loc=loc, model=m, pred_raw=pc, pred_scaled=pcs, save_params=save_params, profile=pname))
+        # ---------------- shard: LPT on the cost model over the items of this run ----------------
+        cost_n = np.where(kind == 2, n_obs, 0)
+        if world_size > 1:
+            parts = sharding.partition_tiles(cost_n, np.where(kind == 2, n_pred if predict else 0, 0), world_size)
+            mine = parts[rank]
+        else:
+            mine = np.arange(len(ex), dtype=np.int64)
+        mine = mine[kind[mine] != 0]                                 # silently skipped locations produce nothing
 
-        # ---------------- pass 2: one packed batch per wave (and per model profile) through the C ABI ----------------
-        out = {k: [] for k in ("run_details", "preds", *self.params_to_store)}
-        res = [None] * len(tiles)                 # per tile: (theta, nll, status, f_mean, f_var, y_var, seconds)
-        for pname, pf in prof.items():
-            members = [i for i, t in enumerate(tiles) if t["profile"] == pname]
-            wave = max_tiles_per_call or max(len(members), 1)
-            for w0 in range(0, len(members), wave):
-                ids = members[w0:w0 + wave]
-                tw = [tiles[i] for i in ids]
-                t0 = time.perf_counter()
-                Ns = np.array([len(t["model"].coords) for t in tw])
-                Ps = np.array([len(t["pred_scaled"]) if predict else 0 for t in tw])
-                obs_off = np.concatenate([[0], np.cumsum(Ns)])
-                pred_off = np.concatenate([[0], np.cumsum(Ps)])
-                X = np.concatenate([t["model"].coords for t in tw]).astype(np.float32)
-                y = np.concatenate([t["model"].obs[:, 0] for t in tw]).astype(np.float32)
-                Xs = np.concatenate([t["pred_scaled"] if predict else np.zeros((0, D)) for t in tw]).astype(np.float32)
-                theta0 = np.stack([t["model"]._theta for t in tw])
-                lo = np.stack([t["model"]._lo for t in tw])
-                hi = np.stack([t["model"]._hi for t in tw])
-                trainable = tw[0]["model"]._trainable
-                r = self.engine.fit_predict_batch(D=D, obs_off=obs_off, X=X, y=y, pred_off=pred_off, Xs=Xs, theta0=theta0,
-                                                  lo=lo, hi=hi, trainable=trainable, kernel=pf["kernel"],
-                                                  optimiser=pf["optimiser"], max_iter=pf["max_iter"], **pf["eng_kw"])
-                dt = (time.perf_counter() - t0) / max(len(tw), 1)
-                for k, i in enumerate(ids):
-                    a_, b_ = pred_off[k], pred_off[k + 1]
-                    res[i] = (r.theta[k], float(r.nll[k]), int(r.status[k]), r.f_mean[a_:b_], r.f_var[a_:b_], r.y_var[a_:b_], dt)
-        for t, rr in zip(tiles, res):              # tables in expert order, whatever the grouping above
-            th, nll_k, st_k, fm, fv, yv, dt = rr
-            m = t["model"]
-            loc = t["loc"]
-            idx1 = _index_for(cc, loc[None, :])
-            out["run_details"].append(pd.DataFrame({
-                "_dim_0": [0], "num_obs": [len(m.coords)], "run_time": [dt], "objective_value": [nll_k],
-                "parameters_optimised": [bool(optimise)], "optimise_success": [bool(optimise and st_k == 0)],
-                "model": [f"{HipGPRModel.__module__}.{HipGPRModel.__name__}"[:64]],
-                "device": [str(m.gpu_name)[:64]], "config_id": [config_id]}, index=idx1))
-            if t["save_params"]:
-                vals = {"lengthscales": th[:D], "kernel_variance": th[D:D + 1], "likelihood_variance": th[D + 1:D + 2]}
-                for pn in self.params_to_store:
-                    v = np.asarray(vals[pn], dtype=np.float64)
-                    out[pn].append(pd.DataFrame({"_dim_0": np.arange(len(v)), pn: v},
-                                                index=_index_for(cc, np.repeat(loc[None, :], len(v), 0))))
-            P = len(fm) if predict else 0
-            if P > 0:
-                pr = {"_dim_0": np.arange(P), "f*": np.asarray(fm, dtype=np.float64),
-                      "f*_var": np.asarray(fv, dtype=np.float64), "y_var": np.asarray(yv, dtype=np.float64),
-                      "f_bar": np.repeat(m.obs_mean[:, 0], P)}
-                for ci, c_ in enumerate(cc):
-                    pr[f"pred_loc_{c_}"] = t["pred_raw"][:, ci]
-                out["preds"].append(pd.DataFrame(pr, index=_index_for(cc, np.repeat(loc[None, :], P, 0))))
-        for loc, n in stubs:
-            out["run_details"].append(pd.DataFrame({
-                "_dim_0": [0], "num_obs": [int(n)], "run_time": [np.nan], "objective_value": [np.nan],
-                "parameters_optimised": [bool(optimise)], "optimise_success": [False],
-                "model": [f"{HipGPRModel.__module__}.{HipGPRModel.__name__}"[:64]], "device": [""],
-                "config_id": [config_id]}, index=_index_for(cc, loc[None, :])))
-        tables = {f"{k}{table_suffix}": (pd.concat(v) if len(v) else pd.DataFrame()) for k, v in out.items()}
-        for k, v in tables.items():
-            store.append(k, v)
+        # ---------------- pass 2: waves ----------------
+        coords_all = self.df.loc[:, cc].values.astype(np.float64)
+        obs_all = self.df[self.obs_col].values.astype(np.float64)
+        assert not np.isnan(coords_all).any(), "nans found in coords"
+        assert not np.isnan(obs_all).any(), "nans found in obs"
+        fixed_rows, pred_rows = [], []
+        self.timings.update(engine_s=0.0, tables_s=0.0, flush_s=0.0)
+        for w0 in range(0, len(mine), wave_n):
+            items = mine[w0:w0 + wave_n]
+            fixed = np.full((len(items), H + 6), np.nan)            # theta, nll, status, n_eval, n_iter, seconds, obs mean
+            preds = [np.zeros((0, 3))] * len(items)
+            for pi in tmpl:
+                loc_ids = np.nonzero((kind[items] == 2) & (prof_id[items] == pi))[0]
+                if len(loc_ids) == 0:
+                    continue
+                ids = items[loc_ids]
+                t_, p_ = tmpl[pi], pinfo[pi]
+                te = time.perf_counter()
+                Ns = n_obs[ids]
+                rows = np.concatenate([idx[off[i]:off[i + 1]] for i in ids])
+                tile_of_row = np.repeat(np.arange(len(ids)), Ns)
+                X = coords_all[rows] / t_["coords_scale"]             # base_model.py:243
+                yv_ = obs_all[rows]
+                o_off = np.concatenate([[0], np.cumsum(Ns)]).astype(np.int64)
+                mean = (np.add.reduceat(yv_, o_off[:-1]) / Ns) if t_["local_mean"] else np.zeros(len(ids))
+                y = (yv_ - mean[tile_of_row]) / t_["obs_scale"]       # base_model.py:244-245
+                Ps = n_pred[ids] if predict else np.zeros(len(ids), dtype=np.int64)
+                p_off = np.concatenate([[0], np.cumsum(Ps)]).astype(np.int64)
+                Xs = np.concatenate([pcs[i] for i in ids]) if predict else np.zeros((0, D))
+                if p_["apply_scale"]:
+                    Xs = Xs / t_["coords_scale"]
+                r = self.engine.fit_predict_batch(D=D, obs_off=o_off, X=X, y=y, pred_off=p_off, Xs=Xs, theta0=theta0[ids],
+                                                  lo=lo[ids], hi=hi[ids], trainable=t_["trainable"], kernel=p_["kernel"],
+                                                  optimiser=p_["optimiser"], max_iter=p_["max_iter"], dtype=self.dtype,
+                                                  **p_["eng_kw"])
+                dt = (time.perf_counter() - te) / len(ids)
+                self.timings["engine_s"] += time.perf_counter() - te
+                fixed[loc_ids, :H] = r.theta
+                fixed[loc_ids, H] = r.nll
+                fixed[loc_ids, H + 1] = r.status
+                fixed[loc_ids, H + 2] = r.n_eval
+                fixed[loc_ids, H + 3] = r.n_iter if getattr(r, "n_iter", None) is not None else np.nan
+                fixed[loc_ids, H + 4] = dt
+                fixed[loc_ids, H + 5] = mean
+                if predict:
+                    pr = np.stack([np.asarray(r.f_mean, dtype=np.float64), np.asarray(r.f_var, dtype=np.float64),
+                                   np.asarray(r.y_var, dtype=np.float64)], axis=1)
+                    for k, j in enumerate(loc_ids):
+                        preds[j] = pr[p_off[k]:p_off[k + 1]]
+            tt = time.perf_counter()
+            pred_cat = np.concatenate(preds) if len(preds) else np.zeros((0, 3))
+            tables = self._tables(ex[items], locs[items], kind[items], n_obs[items], fixed, pred_cat,
+                                  [pcs[i] for i in items] if predict else None, save_params[items],
+                                  [tmpl[p]["device"] for p in prof_id[items]], optimise, config_id, table_suffix)
+            self.timings["tables_s"] += time.perf_counter() - tt
+            tf = time.perf_counter()
+            store.write_wave(tables)                                  # commit: these experts are done
+            self.timings["flush_s"] += time.perf_counter() - tf
+            fixed_rows.append(fixed)
+            pred_rows.append(pred_cat)
+        fixed_all = np.concatenate(fixed_rows) if fixed_rows else np.zeros((0, H + 6))
+        preds_all = np.concatenate(pred_rows) if pred_rows else np.zeros((0, 3))
+
+        # ---------------- gather (world_size > 1): ONE exchange of per-tile results, tables in expert order on rank 0 ----------------
+        if world_size > 1 and gather:
+            cnt = np.where(kind[mine] == 2, n_pred[mine] if predict else 0, 0).astype(np.int64)
+            got = sharding.gather_arrays(fixed_all, preds_all, cnt, mine, len(ex), world_size, rank,
+                                         getattr(self.engine, "device_id", None))
+            if rank == 0:
+                fixed_g, preds_g, _ = got
+                items = np.nonzero(kind != 0)[0]
+                out = self._tables(ex[items], locs[items], kind[items], n_obs[items], fixed_g[items],
+                                   preds_g, [pcs[i] for i in items] if predict else None, save_params[items],
+                                   [tmpl[p]["device"] for p in prof_id[items]], optimise, config_id, table_suffix)
+                self.run_seconds = time.perf_counter() - t_start
+                return out
+        out = self._tables(ex[mine], locs[mine], kind[mine], n_obs[mine], fixed_all, preds_all,
+                           [pcs[i] for i in mine] if predict else None, save_params[mine],
+                           [tmpl[p]["device"] for p in prof_id[mine]], optimise, config_id, table_suffix)
         self.run_seconds = time.perf_counter() - t_start
-        return tables
+        return out
+
+    # ------------------------------------------------------------------------------------------------------
+    def _tables(self, ex_ids, locs, kind, n_obs, fixed, pred_cat, pcs, save_params, devices, optimise, config_id,
+                table_suffix):
+        """Reference-layout tables for a run of items (rows of ``fixed`` align with the items, ``pred_cat`` holds the
+        predictions of the tiles among them back to back).  Pure array assembly (GPSat/local_experts.py:691-747)."""
+        cc = self.coords_col
+        D, H = len(cc), len(cc) + 2
+        n = len(ex_ids)
+        tile = kind == 2
+        status = fixed[:, H + 1]
+        out = {}
+        out["run_details"] = pd.DataFrame({
+            "_dim_0": np.zeros(n, dtype=np.int64), "num_obs": n_obs.astype(np.int64),
+            "run_time": np.where(tile, fixed[:, H + 4], np.nan), "objective_value": np.where(tile, fixed[:, H], np.nan),
+            "parameters_optimised": np.full(n, bool(optimise)),
+            "optimise_success": tile & bool(optimise) & (status == 0),
+            "model": np.full(n, MODEL_NAME, dtype=object),
+            "device": np.array([d if t else "" for d, t in zip(devices, tile)], dtype=object),
+            "config_id": np.full(n, config_id, dtype=np.int64)}, index=_index_for(cc, locs))
+        sp = tile & save_params
+        slots = {"lengthscales": (0, D), "kernel_variance": (D, 1), "likelihood_variance": (D + 1, 1)}
+        for pn in self.params_to_store:
+            start, width = slots[pn]
+            vals = fixed[sp, start:start + width].reshape(-1)
+            out[pn] = pd.DataFrame({"_dim_0": np.tile(np.arange(width), int(sp.sum())), pn: vals},
+                                   index=_index_for(cc, np.repeat(locs[sp], width, axis=0)))
+        if pcs is not None:
+            cnt = np.array([len(p) if t else 0 for p, t in zip(pcs, tile)], dtype=np.int64)
+            tot = int(cnt.sum())
+            assert tot == len(pred_cat), (tot, len(pred_cat))
+            raw = np.concatenate([p for p, t in zip(pcs, tile) if t]) if tot else np.zeros((0, D))
+            dim0 = np.arange(tot) - np.repeat(np.concatenate([[0], np.cumsum(cnt)])[:-1], cnt)
+            pr = {"_dim_0": dim0, "f*": pred_cat[:, 0], "f*_var": pred_cat[:, 1], "y_var": pred_cat[:, 2],
+                  "f_bar": np.repeat(fixed[:, H + 5], cnt)}
+            for ci, c_ in enumerate(cc):
+                pr[f"pred_loc_{c_}"] = raw[:, ci]
+            out["preds"] = pd.DataFrame(pr, index=_index_for(cc, np.repeat(locs, cnt, axis=0)))
+        else:
+            out["preds"] = pd.DataFrame()
+        return {f"{k}{table_suffix}": v for k, v in out.items()}
+
+
+def _dist_rank_world():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except Exception:
+        pass
+    return 0, 1
 
 
 def _jsonable(cfg):
@@ -490,5 +843,7 @@ def _jsonable(cfg):
             return v.tolist()
         if isinstance(v, (np.integer, np.floating)):
             return v.item()
+        if callable(v):
+            return getattr(v, "__name__", repr(v))
         return v
     return conv(cfg or {})

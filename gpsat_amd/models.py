@@ -8,8 +8,9 @@ behaviour as GPSat/models/gpflow_models.py:26-663, but the arithmetic runs in th
 kernels through the C ABI (include/gpsat_hip.h).  There is no CPU fallback.
 
 Differences that are deliberate and documented in DESIGN.md:
-  * compute dtype is fp32 on the GPU (host-side scaling / constraints are fp64 like the reference);
-  * ``mean_function`` and ``full_cov=True`` are not built (NotImplementedError);
+  * compute dtype is fp32 on the GPU by default, ``dtype="f64"`` selects the fp64 kernels (host-side scaling /
+    constraints are always fp64 like the reference);
+  * ``mean_function`` and custom likelihoods are not built (NotImplementedError);
   * no TensorFlow import, no per-construction device probe (the engine knows its device).
 """
 from __future__ import annotations
@@ -50,6 +51,32 @@ def _processor_name():
     return _cpu_name_cache
 
 
+def clamp_within(vals, lo, hi, tol):
+    """Pull values to at least ``tol`` inside the box [lo, hi] (the effect of gpflow_models.py:471-479): ``tol`` is
+    capped at half the narrowest width; the upper side is applied first.  ``vals`` may carry leading batch axes."""
+    margin = min(float(tol), float(np.min(hi - lo)) / 2)
+    vals = np.where(vals > hi - margin, hi - margin, vals)
+    return np.where(vals < lo + margin, lo + margin, vals)
+
+
+def _as_name_list(c):
+    return [c] if isinstance(c, str) else c
+
+
+def _as_columns(a):
+    a = np.array(a)
+    return a[:, None] if a.ndim == 1 else a
+
+
+def _as_scale_row(s):
+    """None -> [[1]]; number -> [[s]]; list -> one row; arrays pass through (base_model.py:212-232)."""
+    if s is None:
+        return np.ones((1, 1))
+    if isinstance(s, (int, float, list)):
+        return np.atleast_2d(np.asarray(s, dtype=np.float64))
+    return np.asarray(s, dtype=np.float64)
+
+
 class HipGPRModel:
     """Exact GP regression for one expert tile on MI355X (mirror of GPflowGPRModel)."""
 
@@ -57,64 +84,39 @@ class HipGPRModel:
                  coords_scale=None, obs_scale=None, obs_mean=None, verbose=True, *,
                  kernel="Matern32", kernel_kwargs=None, mean_function=None, mean_func_kwargs=None,
                  noise_variance=None, likelihood=None, engine=None, dtype="f32", **kwargs):
-        # ---- data intake: GPSat/models/base_model.py:134-189
+        # ---- data intake (behaviour of GPSat/models/base_model.py:134-189): a frame + column names, or bare arrays
         if data is not None:
-            assert coords_col is not None, "data was provided, but coord_col was not"
-            assert obs_col is not None, "data was provided, but obs_col was not"
-            if isinstance(coords_col, str):
-                coords_col = [coords_col]
-            if isinstance(obs_col, str):
-                obs_col = [obs_col]
-            self.obs = np.array(data.loc[:, obs_col].values)
-            self.coords = np.array(data.loc[:, coords_col].values)
-            self.obs_col = obs_col
-            self.coords_col = coords_col
+            if coords_col is None or obs_col is None:
+                missing = "coord_col" if coords_col is None else "obs_col"
+                raise AssertionError(f"data was provided, but {missing} was not")
+            coords_col, obs_col = _as_name_list(coords_col), _as_name_list(obs_col)
+            raw_coords, raw_obs = data.loc[:, coords_col].to_numpy(), data.loc[:, obs_col].to_numpy()
         else:
-            assert obs is not None, f"data is {data}, and so is obs: {obs}, provide either"
-            assert coords is not None, f"data is {data}, and so is coords: {coords}, provide either"
-            assert isinstance(obs, np.ndarray), "if obs is provided directly it must be an np.array"
-            assert isinstance(coords, np.ndarray), "if obs is provided directly it must be an np.array"
-            obs = np.array(obs)
-            coords = np.array(coords)
-            if len(obs.shape) == 1:
-                obs = obs[:, None]
-            if len(coords.shape) == 1:
-                coords = coords[:, None]
-            assert len(obs) == len(coords), "obs and coords lengths don't match "
-            self.obs = obs
-            self.coords = coords
-            if coords_col is None:
-                coords_col = [_ for _ in range(self.coords.shape[1])]
-            if obs_col is None:
-                obs_col = [0]
-            self.coords_col = coords_col
-            self.obs_col = obs_col
-        assert not np.isnan(self.coords).any(), "nans found in coords"
-        assert not np.isnan(self.obs).any(), "nans found in obs"
-        assert self.obs.shape[1] == 1, "HipGPRModel handles a single observation column"
+            for label, arr in (("obs", obs), ("coords", coords)):
+                if arr is None:
+                    raise AssertionError(f"data is {data}, and so is {label}: {arr}, provide either")
+                if not isinstance(arr, np.ndarray):
+                    raise AssertionError(f"if {label} is provided directly it must be an np.array")
+            raw_obs, raw_coords = _as_columns(obs), _as_columns(coords)
+            if len(raw_obs) != len(raw_coords):
+                raise AssertionError("obs and coords lengths don't match ")
+            coords_col = list(range(raw_coords.shape[1])) if coords_col is None else coords_col
+            obs_col = [0] if obs_col is None else obs_col
+        self.coords_col, self.obs_col = coords_col, obs_col
+        for label, arr in (("coords", raw_coords), ("obs", raw_obs)):
+            if np.isnan(arr).any():
+                raise AssertionError(f"nans found in {label}")
+        if raw_obs.shape[1] != 1:
+            raise AssertionError("HipGPRModel handles a single observation column")
 
-        # ---- de-mean / scale: base_model.py:195-245 ("local" -> column mean, anything else -> 0)
-        if isinstance(obs_mean, str) and obs_mean == "local":
-            obs_mean = np.mean(self.obs, axis=0)[None, :]
-        else:
-            obs_mean = np.array([0])[None, :]
-        self.obs_mean = np.asarray(obs_mean, dtype=np.float64)
-        if obs_scale is None:
-            obs_scale = np.atleast_2d(1)
-        elif isinstance(obs_scale, list):
-            obs_scale = np.array(obs_scale)[None, :]
-        elif isinstance(obs_scale, (int, float)):
-            obs_scale = np.array([obs_scale])[None, :]
-        self.obs_scale = np.asarray(obs_scale, dtype=np.float64)
-        if coords_scale is None:
-            coords_scale = np.atleast_2d(1)
-        elif isinstance(coords_scale, list):
-            coords_scale = np.array(coords_scale)[None, :]
-        elif isinstance(coords_scale, (int, float)):
-            coords_scale = np.array([coords_scale])[None, :]
-        self.coords_scale = np.asarray(coords_scale, dtype=np.float64)
-        self.coords = self.coords.astype(np.float64) / self.coords_scale
-        self.obs = (self.obs.astype(np.float64) - self.obs_mean) / self.obs_scale
+        # ---- de-mean / scale (base_model.py:195-245): only the string "local" selects the column mean, every other
+        #      obs_mean (numbers and lists included) means zero; scales become (1, k) rows
+        self.obs_mean = raw_obs.mean(axis=0, keepdims=True).astype(np.float64) \
+            if (isinstance(obs_mean, str) and obs_mean == "local") else np.zeros((1, 1))
+        self.obs_scale = _as_scale_row(obs_scale)
+        self.coords_scale = _as_scale_row(coords_scale)
+        self.coords = np.array(raw_coords, dtype=np.float64) / self.coords_scale
+        self.obs = (np.array(raw_obs, dtype=np.float64) - self.obs_mean) / self.obs_scale
 
         # ---- kernel / defaults: gpflow_models.py:113-157
         assert kernel is not None, "kernel was not provided"
@@ -223,39 +225,29 @@ class HipGPRModel:
 
     def _set_param_constraints(self, name, low, high, move_within_tol=True, tol=1e-8, scale=False,
                                scale_magnitude=None):
-        if isinstance(low, (list, tuple)):
-            low = np.array(low, dtype=np.float64)
-        elif isinstance(low, (int, np.integer, float)):
-            low = np.array([low], dtype=np.float64)
-        if isinstance(high, (list, tuple)):
-            high = np.array(high, dtype=np.float64)
-        elif isinstance(high, (int, np.integer, float)):
-            high = np.array([high], dtype=np.float64)
-        low = np.asarray(low, dtype=np.float64)
-        high = np.asarray(high, dtype=np.float64)
-        assert len(low.shape) == 1
-        assert len(high.shape) == 1
+        """Box for one named parameter (behaviour of gpflow_models.py:416-494): bounds optionally divided by the
+        coordinate scale, the current value pulled to at least ``tol`` inside the box; the sigmoid bijector itself
+        runs on the GPU (lo / hi of the C ABI)."""
         sl = self._slice(name)
-        param_vals = np.atleast_1d(self._theta[sl].copy())
-        assert len(param_vals) == len(low), "len of low constraint does not match param length"
-        assert len(param_vals) == len(high), "len of high constraint does not match param length"
-        assert np.all(low <= high), "all values in high constraint must be greater than low"
+        n = sl.stop - sl.start
+        bounds = []
+        for label, b in (("low", low), ("high", high)):
+            b = np.atleast_1d(np.asarray(b, dtype=np.float64))
+            if b.ndim != 1:
+                raise AssertionError(f"{label} constraint must be a scalar or 1-d")
+            if len(b) != n:
+                raise AssertionError(f"len of {label} constraint does not match param length")
+            bounds.append(b)
+        lo, hi = bounds
+        if not np.all(lo <= hi):
+            raise AssertionError("all values in high constraint must be greater than low")
         if scale:
-            if scale_magnitude is None:
-                low = low / self.coords_scale[0, :]
-                high = high / self.coords_scale[0, :]
-            else:
-                low = low / scale_magnitude
-                high = high / scale_magnitude
+            div = self.coords_scale[0, :] if scale_magnitude is None else scale_magnitude
+            lo, hi = lo / div, hi / div
+        cur = self._theta[sl]
         if move_within_tol:
-            half_min_width = np.min((high - low)) / 2
-            if tol > half_min_width:
-                tol = half_min_width
-            param_vals[param_vals > (high - tol)] = high[param_vals > (high - tol)] - tol
-            param_vals[param_vals < (low + tol)] = low[param_vals < (low + tol)] + tol
-        self._theta[sl] = param_vals
-        self._lo[sl] = low
-        self._hi[sl] = high
+            cur = clamp_within(cur, lo, hi, tol)
+        self._theta[sl], self._lo[sl], self._hi[sl] = cur, lo, hi
 
     def set_lengthscales_constraints(self, low, high, move_within_tol=True, tol=1e-8, scale=False, scale_magnitude=None):
         self._set_param_constraints("lengthscales", low, high, move_within_tol, tol, scale, scale_magnitude)
@@ -298,7 +290,7 @@ class HipGPRModel:
         r = self._run(optimiser=optimiser, max_iter=max_iter, **known)
         self.status = int(r.status[0])
         self.n_eval = int(r.n_eval[0])
-        if self.status in (0, 1):
+        if self.status in (0, 1, 6):
             self._theta = r.theta[0].copy()
         success = self.status == 0
         if not success:

@@ -49,14 +49,48 @@ def pack_subset(batch, idx):
     return out
 
 
-def gather_results(fixed, preds, pred_counts, tile_index, world_size, rank, device=None, dst=0):
+def assemble_global(shards, total=None):
+    """Merge per-shard results into the reference's (global) tile order.
+
+    shards: iterable of (fixed [T_r, F], preds [sumP_r, C], pred_counts [T_r], tile_index [T_r]) numpy arrays, one per
+    shard; tile_index holds the GLOBAL ids of the shard's tiles in the order its rows are packed.
+    Returns (fixed_global [total, F] with NaN rows for tiles no shard owns, preds_global [sumP, C] in global tile order,
+    pred_off_global [total+1]).  Pure host code: the same routine closes the RCCL gather (``gather_results``) and a
+    single-process run over logical shards."""
+    shards = [tuple(np.asarray(a) for a in sh) for sh in shards]
+    if total is None:
+        total = int(sum(len(sh[3]) for sh in shards))
+    F = shards[0][0].shape[1]
+    C = shards[0][1].shape[1] if shards[0][1].ndim == 2 else 3
+    fixed_g = np.full((total, F), np.nan)
+    counts_g = np.zeros(total, dtype=np.int64)
+    for fx, _, cnt, ids in shards:
+        ids = ids.astype(np.int64)
+        assert len(fx) == len(ids) == len(cnt)
+        fixed_g[ids] = fx
+        counts_g[ids] = cnt
+    pred_off_g = np.concatenate([[0], np.cumsum(counts_g)]).astype(np.int64)
+    pdt = np.result_type(*[sh[1].dtype for sh in shards])
+    preds_g = np.zeros((int(pred_off_g[-1]), C), dtype=pdt)
+    for _, pr, cnt, ids in shards:
+        cnt = cnt.astype(np.int64)
+        if cnt.sum() == 0:
+            continue
+        src_off = np.concatenate([[0], np.cumsum(cnt)])[:-1]
+        # destination row of every prediction row of this shard
+        dst = np.repeat(pred_off_g[ids.astype(np.int64)] - src_off, cnt) + np.arange(int(cnt.sum()))
+        preds_g[dst] = pr[:int(cnt.sum())]
+    return fixed_g, preds_g, pred_off_g
+
+
+def gather_results(fixed, preds, pred_counts, tile_index, world_size, rank, device=None, dst=0, total=None):
     """One gather of per-tile results to ``dst``.
 
-    fixed       : [T_r, F] float32 torch tensor (theta, nll, status, n_eval ... per local tile)
-    preds       : [sumP_r, 3] float32 torch tensor (f*, f*_var, y_var)
+    fixed       : [T_r, F] torch tensor (theta, nll, status, n_eval ... per local tile)
+    preds       : [sumP_r, C] torch tensor (f*, f*_var, y_var)
     pred_counts : [T_r] int64 numpy, predictions per local tile
     tile_index  : [T_r] int64 numpy, global tile ids of the local tiles
-    Returns on dst: (fixed_global [T, F], preds_global [sumP, 3] in GLOBAL tile order,
+    Returns on dst: (fixed_global [T, F], preds_global [sumP, C] in GLOBAL tile order,
                      pred_off_global [T+1]); elsewhere None.
     Variable-length parts are padded to the maximum over ranks and moved by ONE all_gather each
     (payloads are tiny against 7 x ~153 GB/s xGMI links; ordering correctness is what matters).
@@ -66,6 +100,7 @@ def gather_results(fixed, preds, pred_counts, tile_index, world_size, rank, devi
 
     dev = fixed.device if device is None else device
     T_r, F = fixed.shape
+    Cp = preds.shape[1]
     meta = torch.tensor([T_r, preds.shape[0]], dtype=torch.int64, device=dev)
     metas = [torch.zeros_like(meta) for _ in range(world_size)]
     dist.all_gather(metas, meta)
@@ -73,9 +108,9 @@ def gather_results(fixed, preds, pred_counts, tile_index, world_size, rank, devi
     Pmax = int(max(m[1].item() for m in metas))
     fx = torch.zeros((Tmax, F + 2), dtype=torch.float64, device=dev)
     fx[:T_r, :F] = fixed.to(torch.float64)
-    fx[:T_r, F] = torch.as_tensor(tile_index, dtype=torch.float64, device=dev)
-    fx[:T_r, F + 1] = torch.as_tensor(pred_counts, dtype=torch.float64, device=dev)
-    pr = torch.zeros((Pmax, 3), dtype=torch.float32, device=dev)
+    fx[:T_r, F] = torch.as_tensor(np.asarray(tile_index), dtype=torch.float64, device=dev)
+    fx[:T_r, F + 1] = torch.as_tensor(np.asarray(pred_counts), dtype=torch.float64, device=dev)
+    pr = torch.zeros((Pmax, Cp), dtype=preds.dtype, device=dev)
     pr[:preds.shape[0]] = preds
     fxs = [torch.zeros_like(fx) for _ in range(world_size)]
     prs = [torch.zeros_like(pr) for _ in range(world_size)]
@@ -83,24 +118,60 @@ def gather_results(fixed, preds, pred_counts, tile_index, world_size, rank, devi
     dist.all_gather(prs, pr)
     if rank != dst:
         return None
-    Ttot = int(sum(m[0].item() for m in metas))
-    fixed_g = np.zeros((Ttot, F))
-    counts_g = np.zeros(Ttot, dtype=np.int64)
-    chunks = {}
+    shards = []
     for r in range(world_size):
-        tr = int(metas[r][0].item())
+        tr, npr = int(metas[r][0].item()), int(metas[r][1].item())
         f = fxs[r][:tr].cpu().numpy()
-        ids = f[:, F].astype(np.int64)
-        cnt = f[:, F + 1].astype(np.int64)
-        fixed_g[ids] = f[:, :F]
-        counts_g[ids] = cnt
-        off = np.concatenate([[0], np.cumsum(cnt)])
-        p = prs[r].cpu().numpy()
-        for k, t in enumerate(ids):
-            chunks[int(t)] = p[off[k]:off[k + 1]]
-    pred_off_g = np.concatenate([[0], np.cumsum(counts_g)])
-    preds_g = np.concatenate([chunks[t] for t in range(Ttot)], axis=0) if Ttot else np.zeros((0, 3), np.float32)
-    return fixed_g, preds_g, pred_off_g
+        shards.append((f[:, :F], prs[r][:npr].cpu().numpy(), f[:, F + 1].astype(np.int64), f[:, F].astype(np.int64)))
+    return assemble_global(shards, total)
+
+
+def gather_arrays(fixed, preds, pred_counts, tile_index, total, world_size, rank, device_id=None, dst=0):
+    """``gather_results`` for host arrays: tensors are staged on this rank's GPU when the process group runs on
+    RCCL ("nccl"), on the host for gloo."""
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cpu")
+    if dist.get_backend() == "nccl":
+        dev = torch.device("cuda", int(device_id or 0))
+    fx = torch.as_tensor(np.ascontiguousarray(fixed, dtype=np.float64), device=dev)
+    pr = torch.as_tensor(np.ascontiguousarray(preds), device=dev)
+    return gather_results(fx, pr, pred_counts, tile_index, world_size, rank, device=dev, dst=dst, total=total)
+
+
+def run_sharded(engine, batch, world_size, rank=None, n_eval=20, **fit_kw):
+    """Partition -> pack -> engine -> results of ONE global packed batch.
+
+    batch: dict with D, obs_off, pred_off, X, y, Xs (host arrays, global tile order) and optionally theta0 / lo / hi
+    [T, H].  With ``rank`` given, this rank's shard is run and (fixed, preds, counts, tile_index) returned for
+    ``gather_results``; with ``rank=None`` all ``world_size`` LOGICAL shards are run one after the other on this
+    engine and merged with ``assemble_global`` -- the single-GPU rehearsal of the multi-GPU path (BASELINE configs[3]).
+    fixed columns: theta (H), nll, status, n_eval, n_iter."""
+    obs_off, pred_off = np.asarray(batch["obs_off"]), np.asarray(batch["pred_off"])
+    D = batch["D"]
+    T = len(obs_off) - 1
+    parts = partition_tiles(np.diff(obs_off), np.diff(pred_off), world_size, n_eval)
+
+    def one(r):
+        ids = parts[r]
+        sub = pack_subset(batch, ids)
+        kw = dict(fit_kw)
+        for k in ("theta0", "lo", "hi"):
+            if k in batch and batch[k] is not None:
+                kw[k] = np.asarray(batch[k])[ids]
+        res = engine.fit_predict_batch(D=D, obs_off=sub["obs_off"], X=sub["X"], y=sub["y"], pred_off=sub["pred_off"],
+                                       Xs=sub["Xs"], **kw)
+        n_iter = res.n_iter if res.n_iter is not None else np.zeros(len(ids))
+        fixed = np.concatenate([res.theta, res.nll[:, None], res.status[:, None].astype(np.float64),
+                                res.n_eval[:, None].astype(np.float64), np.asarray(n_iter, dtype=np.float64)[:, None]], axis=1)
+        preds = np.stack([np.asarray(res.f_mean), np.asarray(res.f_var), np.asarray(res.y_var)], axis=1)
+        return fixed, preds, np.diff(sub["pred_off"]), ids, res
+
+    if rank is not None:
+        return one(rank)
+    shards = [one(r) for r in range(world_size)]
+    fixed_g, preds_g, pred_off_g = assemble_global([s[:4] for s in shards], T)
+    return fixed_g, preds_g, pred_off_g, [s[4] for s in shards]
 
 
 def all_gather_equal(fixed, preds, world_size):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GPSAT_ABI_VERSION 2
+#define GPSAT_ABI_VERSION 3
 
 /* error codes */
 #define GPSAT_OK            0
@@ -65,6 +65,9 @@ extern "C" {
 #define GPSAT_STATUS_NAN       3   /* NaN encountered                                          */
 #define GPSAT_STATUS_SKIPPED   4   /* tile had no observations                                 */
 #define GPSAT_STATUS_NOT_OPTIMISED 5 /* optimiser == NONE: objective + predict only            */
+#define GPSAT_STATUS_LS_FAILED 6   /* line search failed with an empty L-BFGS history (scipy     */
+                                   /*   ABNORMAL_TERMINATION_IN_LNSRCH, success=False); theta is */
+                                   /*   the best sufficient-decrease point seen                   */
 
 typedef struct gpsat_handle gpsat_handle;
 
@@ -99,10 +102,12 @@ typedef struct gpsat_batch {
     int32_t memory;            /* GPSAT_MEM_HOST / GPSAT_MEM_DEVICE for the bulk arrays      */
     int32_t optimiser;         /* GPSAT_OPT_*                                               */
     int32_t max_iter;          /* optimiser iteration limit (scipy options.maxiter)         */
-    int32_t max_ls;            /* max line-search evaluations per iteration (0 = 10; fp64: 20) */
+    int32_t max_ls;            /* max line-search evaluations per iteration (0 = 20, scipy maxls) */
     double  ftol;              /* relative objective decrease tolerance (0 = default: fp64   */
-                               /*   2.2e-9 = SciPy's factr*eps, fp32 1e-6 = its fp32 analogue) */
-    double  gtol;              /* max-norm gradient tolerance in u-space (0 = default 1e-5) */
+                               /*   2.2e-9 = SciPy's factr*eps, fp32 1e-6 = its fp32 analogue; */
+                               /*   negative = never stop on this criterion)                  */
+    double  gtol;              /* max-norm gradient tolerance in u-space (0 = default 1e-5,  */
+                               /*   scipy pgtol; negative = never stop on this criterion)     */
     double  adam_lr;           /* Adam learning rate (0 = default 0.1)                      */
 
     /* ---- metadata: ALWAYS host memory ---- */
@@ -132,6 +137,9 @@ typedef struct gpsat_batch {
     const int64_t *cov_off;    /* [T+1] host: element offsets into f_cov, cov_off[t+1]-cov_off[t] = P_t^2; NULL = off */
     void    *f_cov;            /* [sum P_t^2] host|device (as `memory`), element type `dtype`: per tile the      */
                                /*   row-major P_t x P_t matrix "f*_cov" = K** - K*^T K^-1 K*; NULL = not wanted   */
+
+    /* ---- ABI >= 3 ---- */
+    int32_t *n_iter;           /* [T] host, optional (may be NULL): optimiser iterations completed (scipy nit)  */
 } gpsat_batch;
 
 /* library / ABI version (GPSAT_ABI_VERSION) */

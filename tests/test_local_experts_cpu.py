@@ -93,8 +93,17 @@ def test_selection_edge_semantics():
     out = pl(np.array([0.5, 0.5, 7.0]))
     np.testing.assert_array_equal(out, [[0.0, 0.0, 7.0], [1.0, 1.0, 7.0]])
     assert PredictionLocations(method="expert_loc", coords_col=["x", "y"])(np.array([1.0, 2.0])).tolist() == [[1.0, 2.0]]
-    with pytest.raises(NotImplementedError):
-        PredictionLocations(method="shift_arrays", coords_col=["x"])
+    # shift_arrays: the 'ij' mesh of the per-coordinate shifts (absent coordinates shift by 0) added to the expert
+    # location (prediction_locations.py:182-206)
+    sa = PredictionLocations(method="shift_arrays", coords_col=["x", "y", "t"], x=np.array([-1.0, 0.0, 1.0]), y=[0.0, 10.0])
+    np.testing.assert_array_equal(sa(np.array([5.0, 6.0, 7.0])),
+                                  [[4, 6, 7], [4, 16, 7], [5, 6, 7], [5, 16, 7], [6, 6, 7], [6, 16, 7]])
+    # from_source: loaded once, duplicates dropped, then as from_dataframe (prediction_locations.py:83-101)
+    fs = PredictionLocations(method="from_source", coords_col=["x", "y"], max_dist=2.0,
+                             load_kwargs={"source": pd.DataFrame({"x": [0.0, 0.0, 1.0, 9.0], "y": [0.0, 0.0, 1.0, 9.0]})})
+    np.testing.assert_array_equal(fs(np.array([0.5, 0.5])), [[0.0, 0.0], [1.0, 1.0]])
+    with pytest.raises(ValueError):
+        PredictionLocations(method="no_such_method", coords_col=["x"])
 
 
 def _configs(df, X_grid, radius, locs, noise_std, **model_extra):

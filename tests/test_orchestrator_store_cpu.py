@@ -1,0 +1,172 @@
+"""CPU: the orchestrator's store / resume / sharding contract.
+
+* append-only, atomically committed parts flushed every ``store_every`` expert locations (the reference appends to its
+  HDFStore every ``store_every`` tiles, GPSat/local_experts.py:500-548,1252-1257);
+* a run killed mid-way resumes after the last committed wave and ends with the same tables as an uninterrupted run
+  (GPSat/local_experts.py:475-497,908-912);
+* a world_size-2 tile-sharded run (gloo) gathers to rank 0 the same tables, in the reference's expert order, as an
+  unsharded run (GPSat/local_experts.py:416-420 fixes that order);
+* ``load_params`` variants of GPSat/local_experts.py:553-604 (``index_adjust``, parameters given directly);
+* ``check_prev_oi_config`` (GPSat/utils.py:1276-1327).
+The engine is the oracle behind the packed-batch interface (tests only)."""
+import os
+import socket
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from gpsat_amd import sharding
+from gpsat_amd.local_experts import BatchedLocalExpertOI, ResultStore, check_prev_oi_config, get_results
+from test_local_experts_cpu import OracleEngine, _configs, _notebook_data
+
+
+def _grid_case(n_locs=9):
+    """2-D observations on [0,1]^2 x one time coordinate, experts on a small grid."""
+    rng = np.random.default_rng(5)
+    M = 900
+    df = pd.DataFrame({"x": rng.uniform(0, 1, M), "y": rng.uniform(0, 1, M), "t": rng.uniform(-1, 1, M)})
+    df["z"] = np.sin(4 * df["x"]) * np.cos(3 * df["y"]) + 0.1 * df["t"] + 0.05 * rng.standard_normal(M)
+    g = np.linspace(0.2, 0.8, int(np.sqrt(n_locs)))
+    xl = pd.DataFrame([(a, b, 0.0) for a in g for b in g], columns=["x", "y", "t"])
+    return dict(
+        expert_loc_config={"source": xl},
+        data_config={"data_source": df, "obs_col": "z", "coords_col": ["x", "y", "t"],
+                     "local_select": [{"col": ["x", "y"], "comp": "<", "val": 0.2}, {"col": "t", "comp": "<=", "val": 1},
+                                      {"col": "t", "comp": ">=", "val": -1}]},
+        model_config={"oi_model": "HipGPRModel", "init_params": {"kernel": "Matern32", "obs_mean": "local",
+                                                                 "coords_scale": [0.5, 0.5, 2.0]},
+                      "constraints": {"lengthscales": {"low": [1e-8, 1e-8, 1e-8], "high": [2.0, 2.0, 4.0]}},
+                      "optim_kwargs": {"max_iter": 15}},
+        pred_loc_config={"method": "shift_arrays", "x": np.array([-0.05, 0.0, 0.05]), "y": np.array([0.0, 0.05])})
+
+
+class DyingEngine(OracleEngine):
+    def __init__(self, die_at_call):
+        super().__init__()
+        self.die_at_call = die_at_call
+
+    def fit_predict_batch(self, **kw):
+        if len(self.calls) + 1 == self.die_at_call:
+            raise RuntimeError("simulated fault in the middle of the sweep")
+        return super().fit_predict_batch(**kw)
+
+
+def _assert_same_tables(a, b, ignore=("run_time", "config_id")):
+    assert set(a) == set(b)
+    for k in a:
+        da = a[k].drop(columns=[c for c in ignore if c in a[k].columns])
+        db = b[k].drop(columns=[c for c in ignore if c in b[k].columns])
+        pd.testing.assert_frame_equal(da, db, check_exact=True)
+
+
+def test_flush_every_wave_kill_and_resume(tmp_path):
+    cfg = _grid_case(9)
+    full = BatchedLocalExpertOI(engine=OracleEngine(), **cfg).run(store_path=str(tmp_path / "full"), store_every=2)
+    on_disk = get_results(str(tmp_path / "full"))
+    parts = [f for f in os.listdir(tmp_path / "full") if ".w0" in f]
+    assert len([f for f in parts if f.startswith("run_details.")]) == 5           # 9 experts in waves of 2 -> 5 parts
+    _assert_same_tables(full, {k: v for k, v in on_disk.items() if k in full}, ignore=())
+
+    store = str(tmp_path / "killed")
+    dying = DyingEngine(die_at_call=3)
+    with pytest.raises(RuntimeError):
+        BatchedLocalExpertOI(engine=dying, **cfg).run(store_path=store, store_every=2)
+    partial = get_results(store)
+    assert len(partial["run_details"]) == 4                                       # two committed waves survive the fault
+    # an orphan part (written, never committed) is ignored by readers and removed by the next run
+    pd.DataFrame({"a": [1]}).to_pickle(os.path.join(store, "preds.w000009.r000.pkl"))
+    assert len(get_results(store)["preds"]) == len(partial["preds"])
+    eng = OracleEngine()
+    rest = BatchedLocalExpertOI(engine=eng, **cfg).run(store_path=store, store_every=2)
+    assert not os.path.exists(os.path.join(store, "preds.w000009.r000.pkl"))
+    assert len(rest["run_details"]) == 5 and sum(c["T"] for c in eng.calls) == 5   # only the unfinished experts ran
+    resumed = get_results(store)
+    _assert_same_tables(full, {k: v for k, v in resumed.items() if k in full})
+    # nothing is rewritten by an append: the first two waves' files are the killed run's own
+    assert ResultStore(store).read("run_details").index.equals(full["run_details"].index)
+
+
+def test_load_params_direct_index_adjust_and_config_check(tmp_path):
+    df, X_grid, noise_std = _notebook_data()
+    cfg = _configs(df, X_grid, 0.1, [0.2, 0.4, 0.5], noise_std)
+    store = str(tmp_path / "s")
+    base = BatchedLocalExpertOI(engine=OracleEngine(), **cfg).run(store_path=store)
+    # parameters given directly: set on every tile, nothing optimised
+    cfg_d = _configs(df, X_grid, 0.1, [0.2, 0.4], noise_std, load_params={"lengthscales": [0.05], "kernel_variance": 0.7})
+    t = BatchedLocalExpertOI(engine=OracleEngine(), **cfg_d).run(optimise=False)
+    assert t["lengthscales"]["lengthscales"].tolist() == [0.05, 0.05] and t["kernel_variance"]["kernel_variance"].tolist() == [0.7, 0.7]
+    # index_adjust: the tile at x looks its parameters up at x + 0.1 (the stored 0.5 serves the tile at 0.4; 0.3 has
+    # none -> the tile at 0.2 is skipped, local_experts.py:1099-1101)
+    cfg_a = _configs(df, X_grid, 0.1, [0.2, 0.4], noise_std,
+                     load_params={"file": store, "index_adjust": {"x": {"func": "lambda x: x + 0.1"}}})
+    t = BatchedLocalExpertOI(engine=OracleEngine(), **cfg_a).run(optimise=False, table_suffix="_A")
+    assert t["run_details_A"].index.tolist() == [0.4]
+    assert t["lengthscales_A"]["lengthscales"].iloc[0] == base["lengthscales"]["lengthscales"].loc[0.5]
+    # config bookkeeping: a second run into the same tables with another model config is refused unless told otherwise
+    other = _configs(df, X_grid, 0.1, [0.2, 0.4, 0.5], noise_std)
+    other["model_config"]["init_params"] = {"kernel": "Matern52", "noise_variance": noise_std ** 2}
+    with pytest.raises(AssertionError):
+        BatchedLocalExpertOI(engine=OracleEngine(), **other).run(store_path=store)
+    BatchedLocalExpertOI(engine=OracleEngine(), **other).run(store_path=store, skip_valid_checks_on=["model"])
+    check_prev_oi_config({"a": 1, "b": 2}, {"a": 1, "b": 3}, skip_valid_checks_on=["b"])
+    with pytest.raises(AssertionError):
+        check_prev_oi_config({"a": 1, "b": 2}, {"a": 1, "b": 3})
+
+
+def test_assemble_global_logical_shards():
+    rng = np.random.default_rng(1)
+    T = 37
+    N = rng.choice([64, 128, 500], size=T)
+    P = rng.integers(0, 6, size=T)
+    parts = sharding.partition_tiles(N, P, 3)
+    assert sorted(np.concatenate(parts).tolist()) == list(range(T))
+    shards = []
+    for ids in parts:
+        fx = np.stack([ids * 1.0, ids * 2.0], axis=1)
+        pr = np.concatenate([np.full((P[t], 3), float(t)) + np.arange(P[t])[:, None] * 0.01 for t in ids] + [np.zeros((0, 3))])
+        shards.append((fx, pr, P[ids], ids))
+    fg, pg, off = sharding.assemble_global(shards, T)
+    np.testing.assert_array_equal(fg[:, 0], np.arange(T))
+    np.testing.assert_array_equal(off, np.concatenate([[0], np.cumsum(P)]))
+    for t in range(T):
+        np.testing.assert_allclose(pg[off[t]:off[t + 1], 0], t + np.arange(P[t]) * 0.01)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _sharded_worker(rank, world, port, store, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = _grid_case(16)
+        eng = OracleEngine()
+        tabs = BatchedLocalExpertOI(engine=eng, **cfg).run(store_path=store, store_every=3)    # rank / world from the group
+        ret[f"tiles{rank}"] = sum(c["T"] for c in eng.calls)
+        if rank == 0:
+            ret["tables"] = tabs
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_run_world2_matches_unsharded(tmp_path):
+    import torch.multiprocessing as mp
+    cfg = _grid_case(16)
+    ref = BatchedLocalExpertOI(engine=OracleEngine(), **cfg).run()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    store = str(tmp_path / "sharded")
+    mp.spawn(_sharded_worker, args=(2, _free_port(), store, ret), nprocs=2, join=True)
+    assert ret["tiles0"] > 0 and ret["tiles1"] > 0 and ret["tiles0"] + ret["tiles1"] == len(ref["run_details"])
+    _assert_same_tables(ref, ret["tables"])                     # rank 0: global tables, reference (expert) order
+    # the store holds both ranks' parts; read back in expert order it is the same tables again
+    disk = get_results(store, expert_order=True)
+    _assert_same_tables(ref, {k: v for k, v in disk.items() if k in ref})
