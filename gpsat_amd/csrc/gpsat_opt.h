@@ -148,7 +148,8 @@ static __device__ __noinline__ void ls_step(Shared* sh, int H, int max_ls) {
     }
     sh->ls_iter += 1;
     if (armijo && fabs(dphit) <= -c2 * sh->dphi0) { sh->ls_done = 1; return; }
-    if (sh->ls_iter >= max_ls) { sh->ls_done = (armijo ? 1 : 2); return; }
+    // max_ls evaluations without meeting the strong Wolfe conditions: failure, as L-BFGS-B's `iback >= maxls` (mainlb)
+    if (sh->ls_iter >= max_ls) { sh->ls_done = 2; return; }
     if (sh->ls_phase == 0) {
         if (!armijo || (sh->ls_iter > 1 && ft >= sh->f_prev)) {
             sh->t_lo = sh->t_prev; sh->f_lo = sh->f_prev; sh->dphi_lo = sh->dphi_prev;

@@ -64,7 +64,12 @@ __global__ void __launch_bounds__(256) glue_kernel(int G, int ndim, int nvars, l
         ws += w;
 #pragma unroll
         for (int v = 0; v < GPSAT_GLUE_MAXVARS; ++v)
-            if (v < nvars) acc[v] += w * vals[(size_t)v * R + r];
+            if (v < nvars) {
+                // a NaN prediction (failed tile) is left out of the weighted sum while its weight stays in the
+                // denominator: what the reference's groupby(...).sum() does (it skips NaN), postprocessing.py:512-520
+                const double x = vals[(size_t)v * R + r];
+                if (x == x) acc[v] += w * x;
+            }
     }
     ws = wave_sum(ws);
 #pragma unroll

@@ -3,6 +3,9 @@ predictions.  Host-side mirror of GPSat/postprocessing.py (``smooth_hyperparamet
 ``glue_local_predictions`` / ``_1d`` / ``_2d`` :447-577): same argument names and meaning, tables in / tables out; the
 arithmetic runs in gpsat_post.hip through the C ABI (``gpsat_smooth_batch`` / ``gpsat_glue_batch``).  No CPU fallback:
 without the HIP library these functions raise."""
+import copy
+import json
+import os
 import re
 from typing import Dict, List, Optional, Union
 
@@ -19,13 +22,19 @@ def smooth_hyperparameters(result_file: Union[str, Dict[str, pd.DataFrame]], par
                            smooth_config_dict: Dict[str, dict], xy_dims: List[str] = ("x", "y"),
                            coords_col: Optional[List[str]] = None, reference_table_suffix: str = "",
                            table_suffix: str = "_SMOOTHED", output_file: Optional[str] = None,
-                           all_params: Optional[List[str]] = None, engine=None) -> Dict[str, pd.DataFrame]:
+                           all_params: Optional[List[str]] = None, engine=None,
+                           save_config_file: bool = True) -> Dict[str, pd.DataFrame]:
     """Smooth hyper-parameter tables ``<param><reference_table_suffix>`` of a result store (directory path, or a dict of
     tables) with a 2-D Gaussian over ``xy_dims``, one slice per unique combination of the other coordinates and
     ``_dim_*`` columns; values are clipped to ``smooth_config[param]["max"/"min"]`` first; NaN results are dropped;
     parameters not smoothed are copied.  Writes ``<param><reference_table_suffix><table_suffix>`` tables to
     ``output_file`` (a store directory; default: the input store) and returns them
-    (GPSat/postprocessing.py:215-343)."""
+    (GPSat/postprocessing.py:215-343).  With ``save_config_file`` and a store on disk, the configurations recorded by the
+    runs that produced the tables (``oi_config<reference_table_suffix>.json``) are re-emitted as the predict-only
+    configuration of the next step -- ``run_kwargs.optimise = False``, ``table_suffix`` and ``store_path`` pointing at
+    the smoothed tables, ``model.load_params = {"file", "table_suffix"}`` -- in
+    ``<store>/oi_config<reference_table_suffix><table_suffix>_predict.json`` (GPSat/postprocessing.py:350-380); its path
+    is returned under the key ``"__config_file__"``."""
     eng = engine or default_engine()
     tables = result_file if isinstance(result_file, dict) else ResultStore(result_file).tables()
     if all_params is None:
@@ -67,7 +76,25 @@ def smooth_hyperparameters(result_file: Union[str, Dict[str, pd.DataFrame]], par
     if dest is not None:
         store = ResultStore(dest)
         for k, v in out.items():
-            v.to_pickle(store._file(k))                     # overwrite, like store.put(append=False)
+            store.put(k, v)                                 # overwrite, like store.put(append=False)
+        if save_config_file and isinstance(result_file, str):
+            cfg_in = os.path.join(result_file, f"oi_config{reference_table_suffix}.json")
+            if os.path.exists(cfg_in):
+                new_suffix = f"{reference_table_suffix}{table_suffix}"
+                derived = []
+                for entry in json.load(open(cfg_in)):
+                    oic = copy.deepcopy(entry.get("config", entry))
+                    run_kwargs = dict(entry.get("run_kwargs", {}))
+                    run_kwargs.update(optimise=False, table_suffix=new_suffix, store_path=dest)
+                    model = dict(oic.get("model", {}))
+                    model["load_params"] = {"file": dest, "table_suffix": new_suffix}
+                    oic["model"] = model
+                    oic["run_kwargs"] = run_kwargs
+                    derived.append(oic)
+                cfg_out = os.path.join(dest, f"oi_config{new_suffix}_predict.json")
+                with open(cfg_out, "w") as f:
+                    json.dump(derived, f, indent=4)
+                out["__config_file__"] = cfg_out
     return out
 
 

@@ -16,7 +16,14 @@ Sources of truth (none of them travels to the GPU box; only the .npz outputs do)
 3. ``kat_notebook_rbf.npz`` -- inputs regenerated from the seeds printed in
    docs/notebooks/gp_regression.ipynb (cell 3) together with the values that notebook
    prints (LML 16.6180 -> 21.4700, lengthscale 1.5648, kernel_variance 0.5168).
-4. ``transforms.npz`` -- softplus / sigmoid tables on the grids of tests/test_utils.py:962-1023.
+4. ``transforms.npz`` -- softplus / sigmoid tables on the grids of tests/test_utils.py:962-1023: extended-precision
+   closed forms AND the outputs of the reference's own ``softplus`` / ``sigmoid`` / ``_inverse_softplus`` /
+   ``_inverse_sigmoid`` (GPSat/utils.py:2320-2400; numba is absent, the inert decorator leaves the plain Python bodies
+   of the two inverse kernels, called element by element).
+6. ``kat_sklearn_kernels.npz`` -- scikit-learn (the oracle of the reference's own test, tests/test_localexperts.py:40-49)
+   for the covariance functions that test does not cover: Matern-1/2, Matern-5/2 and RBF with ARD length scales in
+   D = 3, N in {50, 500}: log marginal likelihood and its gradient at two parameter vectors, predictive mean / std /
+   full covariance, and (N = 50) the optimum sklearn's own L-BFGS-B finds.
 5. ``ref_post.npz`` -- outputs of the REFERENCE's gaussian_2d_weight and glue_local_predictions_1d/_2d
    (GPSat/postprocessing.py) on seeded inputs (``python tests/golden/make_golden.py post`` regenerates only this one).
 
@@ -152,33 +159,14 @@ def kat_notebook_rbf():
     print("notebook KAT data written")
 
 
-def transforms():
-    x1 = np.linspace(-100, 100, 1000)
-    x2 = np.linspace(-10, 10, 1000)
-    # closed forms in extended precision as the independent check of the fp64 restatement
-    xl = x1.astype(np.longdouble)
-    sp = np.where(xl > 0, xl + np.log1p(np.exp(-xl)), np.log1p(np.exp(xl))).astype(np.float64)
-    x2l = x2.astype(np.longdouble)
-    sg = (1 / (1 + np.exp(-x2l))).astype(np.float64)
-    np.savez(os.path.join(HERE, "transforms.npz"), x_softplus=x1, softplus=sp, x_sigmoid=x2, sigmoid=sg)
-    print("transform tables written")
-
-
-
-
-def ref_postprocessing():
-    """``ref_post.npz`` -- outputs of the REFERENCE's gaussian_2d_weight body (GPSat/postprocessing.py:28-52; numba
-    is absent, the inert decorator leaves the plain Python function, called once per reference position) and of
-    glue_local_predictions_1d / _2d (:447-577) on seeded inputs."""
-    import pandas as pd
+def _inert_imports():
+    """absent third-party roots resolve to inert placeholder packages; GPSat itself is imported from /root/reference"""
     import importlib.abc
     import importlib.machinery
     roots = {"tensorflow", "tables", "numba", "pyproj", "deprecated", "xarray", "netCDF4", "dataclasses_json", "gpflow",
              "astropy", "global_land_mask", "matplotlib", "cartopy", "seaborn", "gpytorch", "chardet", "shapely"}
 
     class _InertFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
-        """any module below an absent third-party root resolves to an inert placeholder package"""
-
         def find_spec(self, fullname, path, target=None):
             if fullname.split(".")[0] in roots:
                 return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
@@ -190,12 +178,105 @@ def ref_postprocessing():
         def exec_module(self, module):
             module.__path__ = []
 
-    for k in [k for k in sys.modules if k.split(".")[0] in roots]:
-        del sys.modules[k]
-    sys.meta_path.insert(0, _InertFinder())
+    if not any(type(f).__name__ == "_InertFinder" for f in sys.meta_path):
+        for k in [k for k in sys.modules if k.split(".")[0] in roots]:
+            del sys.modules[k]
+        sys.meta_path.insert(0, _InertFinder())
     if REF not in sys.path:
         sys.path.insert(0, REF)
     sys.dont_write_bytecode = True
+
+
+def transforms():
+    x1 = np.linspace(-100, 100, 1000)
+    x2 = np.linspace(-10, 10, 1000)
+    # closed forms in extended precision as the independent check of the fp64 restatement
+    xl = x1.astype(np.longdouble)
+    sp = np.where(xl > 0, xl + np.log1p(np.exp(-xl)), np.log1p(np.exp(xl))).astype(np.float64)
+    x2l = x2.astype(np.longdouble)
+    sg = (1 / (1 + np.exp(-x2l))).astype(np.float64)
+    # the reference's own functions (GPSat/utils.py:2320-2400)
+    _inert_imports()
+    from GPSat import utils as U
+    ref_sp = U.softplus(x1)
+    ref_sp_shift = U.softplus(x1, shift=10.0)
+    ref_sg = U.sigmoid(x2)
+    ref_sg_box = U.sigmoid(x2, -1.0, 2.5)
+
+    def elementwise(body, ys, *consts):
+        out = np.empty(len(ys))
+        o = np.empty(1)
+        for i, v in enumerate(ys):
+            body(np.array([v]), *[np.array([c], dtype=np.float64) for c in consts], o)
+            out[i] = o[0]
+        return out
+    thr = np.log(np.finfo(np.float64).eps) + 2.0
+    y_sp = np.concatenate([ref_sp, [-1.0, 0.0, 1e-300, 1e-20, 40.0, 800.0]])
+    ref_isp = elementwise(U._inverse_softplus, y_sp, 0.0, thr)
+    y_sps = np.concatenate([ref_sp_shift, [9.0, 10.0, 10.0 + 1e-9]])
+    ref_isp_shift = elementwise(U._inverse_softplus, y_sps, 10.0, thr)
+    y_sg = np.concatenate([ref_sg_box, [-1.5, -1.0, 2.5, 3.0]])
+    ref_isg_box = elementwise(U._inverse_sigmoid, y_sg, -1.0, 2.5)
+    np.savez(os.path.join(HERE, "transforms.npz"), x_softplus=x1, softplus=sp, x_sigmoid=x2, sigmoid=sg,
+             ref_softplus=ref_sp, ref_softplus_shift10=ref_sp_shift, ref_sigmoid=ref_sg, ref_sigmoid_box=ref_sg_box,
+             box=np.array([-1.0, 2.5]), y_inv_softplus=y_sp, ref_inv_softplus=ref_isp, y_inv_softplus_shift10=y_sps,
+             ref_inv_softplus_shift10=ref_isp_shift, y_inv_sigmoid_box=y_sg, ref_inv_sigmoid_box=ref_isg_box)
+    print("transform tables written (closed forms + reference functions)")
+
+
+def kat_sklearn_kernels():
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel, Matern
+    out = {}
+    kinds = {"Matern12": lambda ls: Matern(length_scale=ls, nu=0.5), "Matern52": lambda ls: Matern(length_scale=ls, nu=2.5),
+             "RBF": lambda ls: RBF(length_scale=ls)}
+    for N in (50, 500):
+        rng = np.random.default_rng(4200 + N)
+        X = np.column_stack([rng.uniform(-6, 6, N), rng.uniform(-6, 6, N), rng.uniform(-4, 4, N)])
+        Xs = np.column_stack([rng.uniform(-4, 4, 12), rng.uniform(-4, 4, 12), rng.uniform(-1, 1, 12)])
+        f = np.sin(0.6 * X[:, 0]) * np.cos(0.4 * X[:, 1]) + 0.3 * np.sin(0.5 * X[:, 2])
+        y = f + 0.1 * rng.standard_normal(N)
+        y = y - y.mean()
+        out[f"X_{N}"], out[f"y_{N}"], out[f"Xs_{N}"] = X, y, Xs
+        thetas = np.array([[2.5, 4.0, 3.0, 0.6, 0.02], [1.0, 1.0, 1.0, 1.0, 1.0]])      # (l1, l2, l3, sf2, sn2)
+        out[f"thetas_{N}"] = thetas
+        for name, mk in kinds.items():
+            lml, grads, means, stds, covs = [], [], [], [], []
+            for th in thetas:
+                k = ConstantKernel(th[3]) * mk(th[:3].copy())
+                gp = GaussianProcessRegressor(kernel=k, alpha=th[4], optimizer=None).fit(X, y)
+                v, g = gp.log_marginal_likelihood(gp.kernel_.theta, eval_gradient=True)   # gradient w.r.t. log(sf2, l1, l2, l3)
+                lml.append(v)
+                grads.append(g)
+                m, c = gp.predict(Xs, return_cov=True)
+                _, sd = gp.predict(Xs, return_std=True)
+                means.append(m); stds.append(sd); covs.append(c)
+            out[f"{name}_{N}_lml"] = np.array(lml)
+            out[f"{name}_{N}_dlml_dlog"] = np.array(grads)
+            out[f"{name}_{N}_mean"] = np.array(means)
+            out[f"{name}_{N}_std"] = np.array(stds)
+            out[f"{name}_{N}_cov"] = np.array(covs)
+            if N == 50:
+                # sklearn's own optimum (L-BFGS-B on the log parameters, no restarts), noise fixed through alpha
+                k = ConstantKernel(1.0, (1e-3, 1e3)) * mk(np.ones(3))
+                k.k2.length_scale_bounds = (1e-2, 1e2)
+                gp = GaussianProcessRegressor(kernel=k, alpha=0.01, n_restarts_optimizer=0).fit(X, y)
+                out[f"{name}_50_opt_theta"] = np.concatenate([gp.kernel_.k2.length_scale, [gp.kernel_.k1.constant_value, 0.01]])
+                out[f"{name}_50_opt_lml"] = gp.log_marginal_likelihood_value_
+                m, sd = gp.predict(Xs, return_std=True)
+                out[f"{name}_50_opt_mean"], out[f"{name}_50_opt_std"] = m, sd
+            print(f"sklearn {name} N={N}: lml {lml}")
+    np.savez(os.path.join(HERE, "kat_sklearn_kernels.npz"), **out)
+
+
+
+
+def ref_postprocessing():
+    """``ref_post.npz`` -- outputs of the REFERENCE's gaussian_2d_weight body (GPSat/postprocessing.py:28-52; numba
+    is absent, the inert decorator leaves the plain Python function, called once per reference position) and of
+    glue_local_predictions_1d / _2d (:447-577) on seeded inputs."""
+    import pandas as pd
+    _inert_imports()
     from GPSat.postprocessing import gaussian_2d_weight, glue_local_predictions_1d, glue_local_predictions_2d
     rng = np.random.default_rng(77)
     T = 150
@@ -248,9 +329,9 @@ def ref_postprocessing():
 
 
 if __name__ == "__main__":
-    if "post" not in sys.argv[1:]:
-        kat_sklearn()
-        kat_notebook_rbf()
-        transforms()
-        ref_purepython()
-    ref_postprocessing()
+    only = sys.argv[1:]
+    steps = {"sklearn": kat_sklearn, "notebook": kat_notebook_rbf, "purepython": ref_purepython,
+             "transforms": transforms, "kernels": kat_sklearn_kernels, "post": ref_postprocessing}
+    for name, fn in steps.items():          # purepython registers plain stubs; the finder-based imports come after it
+        if not only or name in only:
+            fn()

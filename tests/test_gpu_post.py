@@ -115,6 +115,21 @@ def test_glue_radius_dict_and_errors(eng):
         eng.glue_batch(np.array([0, 2]), np.zeros((1, 3)), np.zeros((1, 3)), np.zeros((1, 3)), 1.0)   # seg != R
 
 
+def test_glue_skips_nan_predictions_like_pandas(eng):
+    """A failed tile writes NaN predictions; the reference's groupby(...).sum() leaves NaN out of the weighted sum and
+    keeps the row's weight in the denominator (GPSat/postprocessing.py:512-520) -- one failed expert must not turn every
+    location it overlaps into NaN."""
+    from gpsat_amd.postprocessing import glue_local_predictions_1d
+    from oracle import post_oracle as po
+    p1 = pd.DataFrame(G["p1"], columns=["x", "pred_loc_x", "f*", "f*_var"]).copy()
+    bad = p1["x"] == np.unique(p1["x"].values)[1]                    # every prediction of one expert
+    p1.loc[bad, ["f*", "f*_var"]] = np.nan
+    got = glue_local_predictions_1d(p1, "pred_loc_x", "x", ["f*", "f*_var"], float(G["r1"]), engine=eng)
+    ref = po.glue_local_predictions(p1, "pred_loc_x", "x", ["f*", "f*_var"], float(G["r1"]))
+    assert np.isfinite(ref["f*"].values).all()
+    np.testing.assert_allclose(got.values, ref.values, rtol=RTOL, atol=1e-14)
+
+
 def test_glue_large_properties(eng):
     """2M rows / 500k locations: single-expert locations pass through unchanged; identical predictions glue to
     themselves; result independent of the row order."""
@@ -172,8 +187,14 @@ def test_fit_smooth_predict_glue_production_loop(eng, tmp_path):
     ls, ls_s = tabs["lengthscales"], sm["lengthscales_SMOOTHED"]
     assert len(ls_s) == len(ls) and ls_s["lengthscales"].std() < ls["lengthscales"].std()
     assert ResultStore(store).read("kernel_variance_SMOOTHED") is not None
+    # the derived predict-only configuration of the next step (GPSat/postprocessing.py:350-380)
+    import json
+    derived = json.load(open(sm["__config_file__"]))
+    assert derived[-1]["run_kwargs"]["optimise"] is False and derived[-1]["run_kwargs"]["table_suffix"] == "_SMOOTHED"
+    assert derived[-1]["model"]["load_params"] == {"file": store, "table_suffix": "_SMOOTHED"}
+    assert derived[-1]["model"]["init_params"]["kernel"] == "Matern32"
     # predict-only with the smoothed parameters loaded per expert location
-    model2 = dict(model, load_params={"file": store, "table_suffix": "_SMOOTHED"})
+    model2 = dict(model, load_params=derived[-1]["model"]["load_params"])
     tabs2 = BatchedLocalExpertOI(model_config=model2, **common).run(store_path=store, optimise=False, table_suffix="_SMOOTHED")
     rd = tabs2["run_details_SMOOTHED"] if "run_details_SMOOTHED" in tabs2 else tabs2["run_details"]
     assert len(rd) == 16 and not rd["optimise_success"].any()                   # optimise=False => success False

@@ -1,0 +1,187 @@
+"""GPU: the HIP path against scikit-learn -- the oracle the reference's own test uses
+(/root/reference/tests/test_localexperts.py:40-49,203-227) -- for the covariance functions that test does not cover
+(Matern-1/2, Matern-5/2, ARD RBF in D = 3; fixtures tests/golden/kat_sklearn_kernels.npz made by
+tests/golden/make_golden.py), the fit tolerances of the reference's CPU-vs-GPU integration check
+(/root/reference/tests/integration.py:109-132: 1e-3 on length scales, 1e-6 on variances) in fp64, and the optimiser's
+status contract against SciPy's L-BFGS-B (success / iteration limit / abnormal line-search termination).
+
+fp64 kernels are held to the reference test's own 1e-6.  fp32 kernels to the stated fp64 -> fp32 tolerance
+(DESIGN.md "Numerics"): |dNLL| <= 2e-5 N + 2e-6 |NLL|, |dgrad| <= 3e-3 (|g| + |g|_inf), |df*| <= 2e-3 max|y|,
+|df*_var| <= 2e-3 sf2 + 1e-6, |dcov| <= 2e-3 sf2.
+"""
+import os
+
+import numpy as np
+import pytest
+from scipy.optimize import minimize
+
+from gpsat_amd import synthetic as syn
+from oracle import gp_oracle as go
+
+pytestmark = pytest.mark.gpu
+
+SK_KERNELS = [("Matern12", 1), ("Matern52", 3), ("RBF", 0)]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from gpsat_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def sk(golden_dir):
+    return np.load(os.path.join(golden_dir, "kat_sklearn_kernels.npz"))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("name,kid", SK_KERNELS)
+@pytest.mark.parametrize("N", [50, 500])
+def test_objective_gradient_predict_cov_vs_sklearn(eng, sk, name, kid, N, dtype):
+    X, y, Xs, thetas = sk[f"X_{N}"], sk[f"y_{N}"], sk[f"Xs_{N}"], sk[f"thetas_{N}"]
+    nT, P = len(thetas), len(Xs)
+    r = eng.fit_predict_batch(D=3, obs_off=np.arange(nT + 1) * N, X=np.tile(X, (nT, 1)), y=np.tile(y, nT),
+                              pred_off=np.arange(nT + 1) * P, Xs=np.tile(Xs, (nT, 1)), theta0=thetas, kernel=name,
+                              optimiser="none", want_grad=True, dtype=dtype, full_cov=True)
+    for i, th in enumerate(thetas):
+        lml = sk[f"{name}_{N}_lml"][i]
+        dl = sk[f"{name}_{N}_dlml_dlog"][i]                       # d LML / d log(sf2, l1, l2, l3)
+        g_ref = np.concatenate([-dl[1:4] / th[:3], [-dl[0] / th[3]]])
+        sl = slice(i * P, (i + 1) * P)
+        cov = np.asarray(r.f_cov[r.cov_off[i]:r.cov_off[i + 1]], dtype=np.float64).reshape(P, P)
+        mean, var, cref = sk[f"{name}_{N}_mean"][i], sk[f"{name}_{N}_std"][i] ** 2, sk[f"{name}_{N}_cov"][i]
+        if dtype == "f64":
+            assert abs(-r.nll[i] - lml) < 1e-6 * max(1.0, abs(lml))
+            np.testing.assert_allclose(r.grad[i][:4], g_ref, rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(r.f_mean[sl], mean, rtol=0, atol=1e-6)
+            np.testing.assert_allclose(r.f_var[sl], var, rtol=0, atol=1e-6)
+            np.testing.assert_allclose(cov, cref, rtol=0, atol=1e-6)
+        else:
+            assert abs(-r.nll[i] - lml) <= 2e-5 * N + 2e-6 * abs(lml)
+            np.testing.assert_array_less(np.abs(r.grad[i][:4] - g_ref), 3e-3 * (np.abs(g_ref) + np.abs(g_ref).max()) + 1e-9)
+            assert np.max(np.abs(r.f_mean[sl] - mean)) <= 2e-3 * np.abs(y).max()
+            assert np.max(np.abs(r.f_var[sl] - var)) <= 2e-3 * th[3] + 1e-6
+            assert np.max(np.abs(cov - cref)) <= 2e-3 * th[3] + 1e-6
+        np.testing.assert_allclose(r.y_var[sl] - r.f_var[sl], th[4], rtol=1e-3, atol=1e-6)
+
+
+def _tight_oracle(name, X, y):
+    m = go.OracleGPR(X, y, kernel=name, noise_variance=0.01)
+    m.set_parameter_constraints({"lengthscales": {"low": [1e-2] * 3, "high": [1e2] * 3}})
+    m.optimise_parameters(fixed_params=["likelihood_variance"], tol=1e-14)
+    return m
+
+
+@pytest.mark.parametrize("name,kid", SK_KERNELS)
+def test_fp64_fit_runs_to_gradient_convergence(eng, sk, name, kid):
+    """Both optimisers run to the gradient tolerance (ftol off): fp64 HIP vs SciPy on the oracle to 1e-3 absolute on the
+    length scales and 1e-6 on the variances (the reference's CPU-vs-GPU tolerances, tests/integration.py:109-132); and vs
+    the optimum sklearn's own fit reports (itself stopped at SciPy's default ftol) to 1e-3 / 1e-5."""
+    from gpsat_amd.models import HipGPRModel
+    X, y, Xs = sk["X_50"], sk["y_50"], sk["Xs_50"]
+    m = HipGPRModel(coords=X, obs=y, kernel=name, noise_variance=0.01, engine=eng, dtype="f64")
+    m.set_parameter_constraints({"lengthscales": {"low": [1e-2] * 3, "high": [1e2] * 3}})
+    m.optimise_parameters(max_iter=2000, fixed_params=["likelihood_variance"], ftol=-1.0, gtol=1e-9)
+    assert m.status in (0, 6), m.status                  # gradient tolerance met, or no step resolvable any more
+    th = np.concatenate([m.get_lengthscales(), [m.get_kernel_variance()]])
+    o = _tight_oracle(name, X, y)
+    np.testing.assert_allclose(th[:3], o.theta[:3], rtol=0, atol=1e-3)
+    assert abs(th[3] - o.theta[3]) < 1e-6
+    assert abs(m.get_objective_function_value() - o.get_objective_function_value()) < 1e-8
+    ref = sk[f"{name}_50_opt_theta"]
+    np.testing.assert_allclose(th[:3], ref[:3], rtol=0, atol=1e-3)
+    assert abs(th[3] - ref[3]) < 1e-5
+    assert abs(-m.get_objective_function_value() - float(sk[f"{name}_50_opt_lml"])) < 1e-6
+    p = m.predict(Xs, apply_scale=False)
+    np.testing.assert_allclose(p["f*"], sk[f"{name}_50_opt_mean"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(np.sqrt(p["f*_var"]), sk[f"{name}_50_opt_std"], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("name,kid", SK_KERNELS)
+def test_fp32_fit_stated_tolerance(eng, sk, name, kid):
+    """fp32 kernels, same problem: the objective carries rounding noise ~ cond(K) eps N, so the optimiser stops on a
+    plateau around the fp64 optimum.  Stated tolerance: objective at the returned parameters (evaluated in fp64) within
+    2e-3 of the fp64 optimum; well-determined parameters (length scales not on the flat far side, kernel variance)
+    within 2 %."""
+    from gpsat_amd.models import HipGPRModel
+    X, y = sk["X_50"], sk["y_50"]
+    m = HipGPRModel(coords=X, obs=y, kernel=name, noise_variance=0.01, engine=eng, dtype="f32")
+    m.set_parameter_constraints({"lengthscales": {"low": [1e-2] * 3, "high": [1e2] * 3}})
+    m.optimise_parameters(max_iter=500, fixed_params=["likelihood_variance"])
+    assert m.status in (0, 6)
+    o = _tight_oracle(name, X, y)
+    th = np.concatenate([m.get_lengthscales(), [m.get_kernel_variance(), 0.01]])
+    f_at = go.nll_and_grad(kid, X, y, th, want_grad=False)[0]
+    assert f_at - o.get_objective_function_value() < 2e-3
+    np.testing.assert_allclose(th[:2], o.theta[:2], rtol=2e-2)
+    np.testing.assert_allclose(th[3], o.theta[3], rtol=2e-2)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# optimiser status contract vs SciPy
+# ------------------------------------------------------------------------------------------------------------------
+def _scipy(kid, X, y, th0, lo, hi, **options):
+    shift = np.where(np.isfinite(lo), 0.0, np.array([0.0] * (len(th0) - 1) + [go.LIK_VAR_LOWER]))
+    u0 = go.u_from_theta(th0, lo, hi, shift)
+
+    def fun(u):
+        th = go.theta_from_u(u, lo, hi, shift)
+        f, g = go.nll_and_grad(kid, X, y, th)
+        return f, g * go.dtheta_du(th, lo, hi, shift)
+    return minimize(fun, u0, jac=True, method="L-BFGS-B", options=options), fun, u0
+
+
+def test_status_follows_scipy(eng):
+    """(a) iteration limit -> status 1 and n_iter == max_iter (SciPy: success False, nit == maxiter);
+    (b) convergence -> status 0 (success True), n_iter within a few of SciPy's nit;
+    (c) a line search that cannot finish -> status 6 = SciPy's ABNORMAL_TERMINATION_IN_LNSRCH (success False), the best
+        sufficient-decrease point is returned, never the starting point labelled 'converged'."""
+    D, kid = 2, 2
+    lo = np.full(D + 2, -np.inf)
+    hi = np.full(D + 2, np.inf)
+    found = None
+    for seed in range(40):
+        X, y, _, _ = syn.make_tile(7000 + seed, 60, 0, D, kid)
+        th0 = np.array([0.3, 0.3, 2.0, 0.5])
+        res, fun, u0 = _scipy(kid, X, y, th0, lo, hi, maxls=1, maxiter=50)
+        f0, g0 = fun(u0)
+        t = min(1.0, 1.0 / np.sqrt(g0 @ g0))
+        f1, _ = fun(u0 - t * g0)
+        if not res.success and f1 > f0 + 1e-4 * t * (-(g0 @ g0)):          # first trial violates sufficient decrease
+            found = (X, y, th0, res)
+            break
+    assert found is not None
+    X, y, th0, res = found
+    kw = dict(D=D, obs_off=np.array([0, len(y)]), X=X, y=y, pred_off=np.array([0, 0]), Xs=np.zeros((0, D)),
+              theta0=th0[None], kernel="Matern32", optimiser="lbfgs", dtype="f64")
+    r = eng.fit_predict_batch(max_iter=50, max_ls=1, **kw)
+    assert "ABNORMAL" in str(res.message) and not res.success
+    assert r.status[0] == 6 and r.n_iter[0] == 0
+    np.testing.assert_array_equal(r.theta[0], th0)                          # no sufficient-decrease point was seen
+    # (a) iteration limit
+    res_a, _, _ = _scipy(kid, X, y, th0, lo, hi, maxiter=3)
+    ra = eng.fit_predict_batch(max_iter=3, **kw)
+    assert not res_a.success and res_a.nit == 3 and ra.status[0] == 1 and ra.n_iter[0] == 3
+    # (b) convergence
+    res_b, _, _ = _scipy(kid, X, y, th0, lo, hi, maxiter=1000)
+    rb = eng.fit_predict_batch(max_iter=1000, **kw)
+    assert res_b.success and rb.status[0] == 0 and abs(int(rb.n_iter[0]) - res_b.nit) <= max(5, res_b.nit // 2)
+    shift = np.array([0.0, 0.0, 0.0, go.LIK_VAR_LOWER])
+    np.testing.assert_allclose(rb.theta[0], go.theta_from_u(res_b.x, lo, hi, shift), rtol=2e-3, atol=1e-6)
+    assert rb.nll[0] == pytest.approx(res_b.fun, abs=1e-6)
+
+
+def test_exact_iteration_count_mode(eng):
+    """ftol = gtol = off: every tile runs exactly max_iter iterations unless its line search fails (the bench's
+    'exact-iters' mode); n_eval >= n_iter + 1."""
+    T, N, P, D = 16, 200, 8, 3
+    b = syn.make_batch(T, N, P, D, 0, base_seed=4242)
+    lo, hi = syn.default_bounds(T, D)
+    r = eng.fit_predict_batch(D=D, obs_off=b["obs_off"], X=b["X"], y=b["y"], pred_off=b["pred_off"], Xs=b["Xs"],
+                              theta0=np.ones((T, D + 2)), lo=lo, hi=hi, kernel="RBF", optimiser="lbfgs", max_iter=20,
+                              ftol=-1.0, gtol=-1.0)
+    assert set(np.unique(r.status)) <= {1, 6}
+    assert (r.n_iter[r.status == 1] == 20).all() and (r.n_eval >= r.n_iter + 1).all()
+    assert (r.status == 1).mean() >= 0.75

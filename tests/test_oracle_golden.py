@@ -115,3 +115,71 @@ def test_gradient_chain_all_kernels():
         fd = np.array([(f(u + 1e-6 * e) - f(u - 1e-6 * e)) / 2e-6 for e in np.eye(D + 2)])
         np.testing.assert_allclose(gu, fd, rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(go.u_from_theta(go.theta_from_u(u, lo, hi, shift), lo, hi, shift), u, atol=1e-9)
+
+
+def test_transforms_against_reference_functions(golden_dir):
+    """The oracle's transforms against the outputs of the reference's OWN functions (GPSat/utils.py:2320-2400, generated
+    by tests/golden/make_golden.py), at the tolerances of the reference's tests (tests/test_utils.py:962-1023),
+    including the out-of-range values (-inf at / below the lower bound, +inf at / above the upper one)."""
+    g = _load(golden_dir, "transforms.npz")
+    np.testing.assert_array_almost_equal(go.softplus(g["x_softplus"]), g["ref_softplus"], decimal=14)
+    np.testing.assert_array_almost_equal(go.softplus(g["x_softplus"], shift=10.0), g["ref_softplus_shift10"], decimal=14)
+    np.testing.assert_array_almost_equal(go.sigmoid(g["x_sigmoid"]), g["ref_sigmoid"], decimal=14)
+    lo, hi = g["box"]
+    np.testing.assert_array_almost_equal(go.sigmoid(g["x_sigmoid"], lo, hi), g["ref_sigmoid_box"], decimal=14)
+    for y, ref, kw in ((g["y_inv_softplus"], g["ref_inv_softplus"], {}),
+                       (g["y_inv_softplus_shift10"], g["ref_inv_softplus_shift10"], {"shift": 10.0})):
+        got = go.inverse_softplus(y, **kw)
+        fin = np.isfinite(ref)
+        assert (np.isfinite(got) == fin).all() and (got[~fin] == ref[~fin]).all()
+        np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-14, atol=1e-14)
+    got = go.inverse_sigmoid(g["y_inv_sigmoid_box"], lo, hi)
+    ref = g["ref_inv_sigmoid_box"]
+    fin = np.isfinite(ref)
+    assert (np.isfinite(got) == fin).all() and (got[~fin] == ref[~fin]).all()
+    np.testing.assert_allclose(got[fin], ref[fin], rtol=0, atol=1e-12)
+
+
+SK_KERNELS = [("Matern12", 1), ("Matern52", 3), ("RBF", 0)]
+
+
+@pytest.mark.parametrize("name,kid", SK_KERNELS)
+@pytest.mark.parametrize("N", [50, 500])
+def test_sklearn_kernels_d3(golden_dir, name, kid, N):
+    """Matern-1/2, Matern-5/2 and ARD RBF in D = 3 against scikit-learn -- the oracle of the reference's own test
+    (tests/test_localexperts.py:40-49,203-227) -- at that test's tolerance (1e-6): objective, its gradient,
+    predictive mean / variance / full covariance."""
+    g = _load(golden_dir, "kat_sklearn_kernels.npz")
+    X, y, Xs = g[f"X_{N}"], g[f"y_{N}"], g[f"Xs_{N}"]
+    for i, th in enumerate(g[f"thetas_{N}"]):
+        nll, grad = go.nll_and_grad(kid, X, y, th)
+        assert abs(-nll - g[f"{name}_{N}_lml"][i]) < 1e-6 * max(1.0, abs(nll))
+        # sklearn: d LML / d log(sf2, l1, l2, l3)  ->  dNLL/dtheta_j = -(.)/theta_j
+        dl = g[f"{name}_{N}_dlml_dlog"][i]
+        ref_grad = np.concatenate([-dl[1:4] / th[:3], [-dl[0] / th[3]]])
+        np.testing.assert_allclose(grad[:4], ref_grad, rtol=1e-6, atol=1e-6)
+        f, fv, yv = go.predict(kid, X, y, Xs, th)
+        np.testing.assert_allclose(f, g[f"{name}_{N}_mean"][i], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(fv, g[f"{name}_{N}_std"][i] ** 2, rtol=0, atol=1e-6)
+        fc, _ = go.predict_cov(kid, X, y, Xs, th)
+        np.testing.assert_allclose(fc, g[f"{name}_{N}_cov"][i], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,kid", SK_KERNELS)
+def test_sklearn_optimum_d3(golden_dir, name, kid):
+    """The multi-parameter optimum sklearn's own L-BFGS-B finds (4 trainable scalars, noise fixed) is the oracle's: run to
+    the gradient tolerance, length scales to 1e-3 and variances to 1e-6 as the reference's integration check asks
+    (tests/integration.py:109-132)."""
+    g = _load(golden_dir, "kat_sklearn_kernels.npz")
+    X, y, Xs = g["X_50"], g["y_50"], g["Xs_50"]
+    ref = g[f"{name}_50_opt_theta"]
+    m = go.OracleGPR(X, y, kernel=name, noise_variance=0.01)
+    m.set_parameter_constraints({"lengthscales": {"low": [1e-2] * 3, "high": [1e2] * 3}})
+    assert m.optimise_parameters(fixed_params=["likelihood_variance"], tol=1e-14)
+    assert abs(-m.get_objective_function_value() - float(g[f"{name}_50_opt_lml"])) < 1e-7
+    th = m.theta
+    np.testing.assert_allclose(th[:3], ref[:3], rtol=0, atol=1e-3)      # sklearn itself stops at SciPy's default ftol
+    assert abs(th[3] - ref[3]) < 1e-5
+    f, fv, _ = go.predict(kid, X, y, Xs, th)
+    np.testing.assert_allclose(f, g[f"{name}_50_opt_mean"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(np.sqrt(fv), g[f"{name}_50_opt_std"], rtol=0, atol=1e-4)
