@@ -577,10 +577,18 @@ class BatchedLocalExpertOI:
         """See the module docstring.  ``store_every``: expert locations per flushed wave (default 4096;
         ``max_tiles_per_call`` is the older name of the same knob).  ``rank`` / ``world_size``: tile-sharded run, one
         process per GPU (default: taken from an initialised ``torch.distributed`` group, else 0 / 1); with
-        ``gather=True`` rank 0 returns the global tables in expert order, the other ranks their own shard's."""
+        ``gather=True`` rank 0 returns the global tables in expert order, the other ranks their own shard's.
+        ``world_size > 1`` with ``rank=None`` and no process group runs all the LOGICAL shards one after the other on
+        this process's engine and merges them with the routine that closes the gather -- the one-GPU rehearsal of the
+        multi-GPU path."""
         t_start = time.perf_counter()
-        if rank is None or world_size is None:
-            rank, world_size = _dist_rank_world()
+        d_rank, d_world = _dist_rank_world()
+        logical = world_size is not None and world_size > 1 and rank is None and d_world == 1
+        if logical:
+            rank = 0
+        elif rank is None or world_size is None:
+            rank, world_size = d_rank, d_world
+        in_group = (not logical) and world_size > 1 and d_world == world_size
         store = ResultStore(store_path, rank=rank)
         cc = self.coords_col
         D, H = len(cc), len(cc) + 2
@@ -595,6 +603,10 @@ class BatchedLocalExpertOI:
             if prev and check_config_compatible:
                 check_prev_oi_config(prev[-1]["config"], self.config, skip_valid_checks_on)
             config_id = len(prev) + 1
+            done = store.read(f"run_details{table_suffix}")          # resume state, read before any rank writes
+            if in_group:
+                import torch.distributed as dist
+                dist.barrier()
             if rank == 0:
                 prev.append({"idx": config_id, "datetime": time.strftime("%Y-%m-%d %H:%M:%S"), "config": self.config,
                              "run_kwargs": {"optimise": optimise, "predict": predict, "min_obs": min_obs,
@@ -606,7 +618,8 @@ class BatchedLocalExpertOI:
                     store.put(f"expert_locs{table_suffix}", xl.set_index(cc))
         # ---- resume: drop expert locations already in run_details (local_experts.py:475-497,908-912)
         todo = np.ones(len(xl), dtype=bool)
-        done = store.read(f"run_details{table_suffix}")
+        if not store_path:
+            done = None
         if done is not None and len(done):
             todo = ~np.asarray(_index_for(cc, xl[cc].values.astype(np.float64)).isin(done.index))
         ex = np.nonzero(todo)[0]                                   # global expert positions still to run
@@ -692,90 +705,104 @@ class BatchedLocalExpertOI:
         cost_n = np.where(kind == 2, n_obs, 0)
         if world_size > 1:
             parts = sharding.partition_tiles(cost_n, np.where(kind == 2, n_pred if predict else 0, 0), world_size)
-            mine = parts[rank]
         else:
-            mine = np.arange(len(ex), dtype=np.int64)
-        mine = mine[kind[mine] != 0]                                 # silently skipped locations produce nothing
+            parts = [np.arange(len(ex), dtype=np.int64)]
+        parts = [p_[kind[p_] != 0] for p_ in parts]                  # silently skipped locations produce nothing
 
-        # ---------------- pass 2: waves ----------------
         coords_all = self.df.loc[:, cc].values.astype(np.float64)
         obs_all = self.df[self.obs_col].values.astype(np.float64)
         assert not np.isnan(coords_all).any(), "nans found in coords"
         assert not np.isnan(obs_all).any(), "nans found in obs"
-        fixed_rows, pred_rows = [], []
         self.timings.update(engine_s=0.0, tables_s=0.0, flush_s=0.0)
-        for w0 in range(0, len(mine), wave_n):
-            items = mine[w0:w0 + wave_n]
-            fixed = np.full((len(items), H + 6), np.nan)            # theta, nll, status, n_eval, n_iter, seconds, obs mean
-            preds = [np.zeros((0, 3))] * len(items)
-            for pi in tmpl:
-                loc_ids = np.nonzero((kind[items] == 2) & (prof_id[items] == pi))[0]
-                if len(loc_ids) == 0:
-                    continue
-                ids = items[loc_ids]
-                t_, p_ = tmpl[pi], pinfo[pi]
-                te = time.perf_counter()
-                Ns = n_obs[ids]
-                rows = np.concatenate([idx[off[i]:off[i + 1]] for i in ids])
-                tile_of_row = np.repeat(np.arange(len(ids)), Ns)
-                X = coords_all[rows] / t_["coords_scale"]             # base_model.py:243
-                yv_ = obs_all[rows]
-                o_off = np.concatenate([[0], np.cumsum(Ns)]).astype(np.int64)
-                mean = (np.add.reduceat(yv_, o_off[:-1]) / Ns) if t_["local_mean"] else np.zeros(len(ids))
-                y = (yv_ - mean[tile_of_row]) / t_["obs_scale"]       # base_model.py:244-245
-                Ps = n_pred[ids] if predict else np.zeros(len(ids), dtype=np.int64)
-                p_off = np.concatenate([[0], np.cumsum(Ps)]).astype(np.int64)
-                Xs = np.concatenate([pcs[i] for i in ids]) if predict else np.zeros((0, D))
-                if p_["apply_scale"]:
-                    Xs = Xs / t_["coords_scale"]
-                r = self.engine.fit_predict_batch(D=D, obs_off=o_off, X=X, y=y, pred_off=p_off, Xs=Xs, theta0=theta0[ids],
-                                                  lo=lo[ids], hi=hi[ids], trainable=t_["trainable"], kernel=p_["kernel"],
-                                                  optimiser=p_["optimiser"], max_iter=p_["max_iter"], dtype=self.dtype,
-                                                  **p_["eng_kw"])
-                dt = (time.perf_counter() - te) / len(ids)
-                self.timings["engine_s"] += time.perf_counter() - te
-                fixed[loc_ids, :H] = r.theta
-                fixed[loc_ids, H] = r.nll
-                fixed[loc_ids, H + 1] = r.status
-                fixed[loc_ids, H + 2] = r.n_eval
-                fixed[loc_ids, H + 3] = r.n_iter if getattr(r, "n_iter", None) is not None else np.nan
-                fixed[loc_ids, H + 4] = dt
-                fixed[loc_ids, H + 5] = mean
-                if predict:
-                    pr = np.stack([np.asarray(r.f_mean, dtype=np.float64), np.asarray(r.f_var, dtype=np.float64),
-                                   np.asarray(r.y_var, dtype=np.float64)], axis=1)
-                    for k, j in enumerate(loc_ids):
-                        preds[j] = pr[p_off[k]:p_off[k + 1]]
-            tt = time.perf_counter()
-            pred_cat = np.concatenate(preds) if len(preds) else np.zeros((0, 3))
-            tables = self._tables(ex[items], locs[items], kind[items], n_obs[items], fixed, pred_cat,
-                                  [pcs[i] for i in items] if predict else None, save_params[items],
-                                  [tmpl[p]["device"] for p in prof_id[items]], optimise, config_id, table_suffix)
-            self.timings["tables_s"] += time.perf_counter() - tt
-            tf = time.perf_counter()
-            store.write_wave(tables)                                  # commit: these experts are done
-            self.timings["flush_s"] += time.perf_counter() - tf
-            fixed_rows.append(fixed)
-            pred_rows.append(pred_cat)
-        fixed_all = np.concatenate(fixed_rows) if fixed_rows else np.zeros((0, H + 6))
-        preds_all = np.concatenate(pred_rows) if pred_rows else np.zeros((0, 3))
 
-        # ---------------- gather (world_size > 1): ONE exchange of per-tile results, tables in expert order on rank 0 ----------------
-        if world_size > 1 and gather:
+        def tables_for(items, fixed, pred_cat):
+            return self._tables(ex[items], locs[items], kind[items], n_obs[items], fixed, pred_cat,
+                                [pcs[i] for i in items] if predict else None, save_params[items],
+                                [tmpl[p]["device"] for p in prof_id[items]], optimise, config_id, table_suffix)
+
+        # ---------------- pass 2: waves of one shard ----------------
+        def run_shard(mine, shard_store):
+            fixed_rows, pred_rows = [], []
+            for w0 in range(0, len(mine), wave_n):
+                items = mine[w0:w0 + wave_n]
+                fixed = np.full((len(items), H + 6), np.nan)        # theta, nll, status, n_eval, n_iter, seconds, obs mean
+                preds = [np.zeros((0, 3))] * len(items)
+                for pi in tmpl:
+                    loc_ids = np.nonzero((kind[items] == 2) & (prof_id[items] == pi))[0]
+                    if len(loc_ids) == 0:
+                        continue
+                    ids = items[loc_ids]
+                    t_, p_ = tmpl[pi], pinfo[pi]
+                    te = time.perf_counter()
+                    Ns = n_obs[ids]
+                    rows = np.concatenate([idx[off[i]:off[i + 1]] for i in ids])
+                    tile_of_row = np.repeat(np.arange(len(ids)), Ns)
+                    X = coords_all[rows] / t_["coords_scale"]         # base_model.py:243
+                    yv_ = obs_all[rows]
+                    o_off = np.concatenate([[0], np.cumsum(Ns)]).astype(np.int64)
+                    mean = (np.add.reduceat(yv_, o_off[:-1]) / Ns) if t_["local_mean"] else np.zeros(len(ids))
+                    y = (yv_ - mean[tile_of_row]) / t_["obs_scale"]   # base_model.py:244-245
+                    Ps = n_pred[ids] if predict else np.zeros(len(ids), dtype=np.int64)
+                    p_off = np.concatenate([[0], np.cumsum(Ps)]).astype(np.int64)
+                    Xs = np.concatenate([pcs[i] for i in ids]) if predict else np.zeros((0, D))
+                    if p_["apply_scale"]:
+                        Xs = Xs / t_["coords_scale"]
+                    r = self.engine.fit_predict_batch(D=D, obs_off=o_off, X=X, y=y, pred_off=p_off, Xs=Xs,
+                                                      theta0=theta0[ids], lo=lo[ids], hi=hi[ids],
+                                                      trainable=t_["trainable"], kernel=p_["kernel"],
+                                                      optimiser=p_["optimiser"], max_iter=p_["max_iter"],
+                                                      dtype=self.dtype, **p_["eng_kw"])
+                    dt = (time.perf_counter() - te) / len(ids)
+                    self.timings["engine_s"] += time.perf_counter() - te
+                    fixed[loc_ids, :H] = r.theta
+                    fixed[loc_ids, H] = r.nll
+                    fixed[loc_ids, H + 1] = r.status
+                    fixed[loc_ids, H + 2] = r.n_eval
+                    fixed[loc_ids, H + 3] = r.n_iter if getattr(r, "n_iter", None) is not None else np.nan
+                    fixed[loc_ids, H + 4] = dt
+                    fixed[loc_ids, H + 5] = mean
+                    if predict:
+                        pr = np.stack([np.asarray(r.f_mean, dtype=np.float64), np.asarray(r.f_var, dtype=np.float64),
+                                       np.asarray(r.y_var, dtype=np.float64)], axis=1)
+                        for k, j in enumerate(loc_ids):
+                            preds[j] = pr[p_off[k]:p_off[k + 1]]
+                tt = time.perf_counter()
+                pred_cat = np.concatenate(preds) if len(preds) else np.zeros((0, 3))
+                tables = tables_for(items, fixed, pred_cat)
+                self.timings["tables_s"] += time.perf_counter() - tt
+                tf = time.perf_counter()
+                shard_store.write_wave(tables)                        # commit: these experts are done
+                self.timings["flush_s"] += time.perf_counter() - tf
+                fixed_rows.append(fixed)
+                pred_rows.append(pred_cat)
+            fixed_all = np.concatenate(fixed_rows) if fixed_rows else np.zeros((0, H + 6))
+            preds_all = np.concatenate(pred_rows) if pred_rows else np.zeros((0, 3))
             cnt = np.where(kind[mine] == 2, n_pred[mine] if predict else 0, 0).astype(np.int64)
-            got = sharding.gather_arrays(fixed_all, preds_all, cnt, mine, len(ex), world_size, rank,
-                                         getattr(self.engine, "device_id", None))
-            if rank == 0:
-                fixed_g, preds_g, _ = got
-                items = np.nonzero(kind != 0)[0]
-                out = self._tables(ex[items], locs[items], kind[items], n_obs[items], fixed_g[items],
-                                   preds_g, [pcs[i] for i in items] if predict else None, save_params[items],
-                                   [tmpl[p]["device"] for p in prof_id[items]], optimise, config_id, table_suffix)
-                self.run_seconds = time.perf_counter() - t_start
-                return out
-        out = self._tables(ex[mine], locs[mine], kind[mine], n_obs[mine], fixed_all, preds_all,
-                           [pcs[i] for i in mine] if predict else None, save_params[mine],
-                           [tmpl[p]["device"] for p in prof_id[mine]], optimise, config_id, table_suffix)
+            return fixed_all, preds_all, cnt, mine
+
+        all_items = np.nonzero(kind != 0)[0]
+        if logical:
+            # every logical shard on this engine, merged by the routine that closes the gather
+            shards = []
+            for r_ in range(world_size):
+                st_r = ResultStore(store_path, rank=r_)
+                st_r.drop_uncommitted()
+                shards.append(run_shard(parts[r_], st_r))
+            fixed_g, preds_g, _ = sharding.assemble_global(shards, len(ex))
+            out = tables_for(all_items, fixed_g[all_items], preds_g)
+        else:
+            mine = parts[rank] if world_size > 1 else parts[0]
+            fixed_all, preds_all, cnt, _ = run_shard(mine, store)
+            out = None
+            if world_size > 1 and gather:
+                # ONE exchange of per-tile results (RCCL over xGMI on the GPU node); tables in expert order on rank 0
+                got = sharding.gather_arrays(fixed_all, preds_all, cnt, mine, len(ex), world_size, rank,
+                                             getattr(self.engine, "device_id", None))
+                if rank == 0:
+                    fixed_g, preds_g, _ = got
+                    out = tables_for(all_items, fixed_g[all_items], preds_g)
+            if out is None:
+                out = tables_for(mine, fixed_all, preds_all)
         self.run_seconds = time.perf_counter() - t_start
         return out
 

@@ -170,3 +170,16 @@ def test_sharded_run_world2_matches_unsharded(tmp_path):
     # the store holds both ranks' parts; read back in expert order it is the same tables again
     disk = get_results(store, expert_order=True)
     _assert_same_tables(ref, {k: v for k, v in disk.items() if k in ref})
+
+
+def test_logical_shards_in_one_process(tmp_path):
+    """world_size=3 without a process group: the three logical shards run one after the other and are merged by the
+    routine that closes the gather -- the same tables as the unsharded run, each shard's parts committed under its rank."""
+    cfg = _grid_case(16)
+    ref = BatchedLocalExpertOI(engine=OracleEngine(), **cfg).run()
+    store = str(tmp_path / "logical")
+    eng = OracleEngine()
+    got = BatchedLocalExpertOI(engine=eng, **cfg).run(store_path=store, store_every=4, world_size=3)
+    _assert_same_tables(ref, got)
+    assert {f.split(".")[2] for f in os.listdir(store) if f.startswith("run_details.w")} == {"r000", "r001", "r002"}
+    _assert_same_tables(ref, {k: v for k, v in get_results(store, expert_order=True).items() if k in ref})
