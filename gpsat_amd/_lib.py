@@ -23,7 +23,7 @@ STATUS = {0: "converged", 1: "max_iter", 2: "not_pd", 3: "nan", 4: "skipped", 5:
 
 EXPORTS = ["gpsat_version", "gpsat_last_error", "gpsat_device_count", "gpsat_create", "gpsat_device_name",
            "gpsat_destroy", "gpsat_fit_predict_batch", "gpsat_last_timing", "gpsat_select_batch",
-           "gpsat_smooth_batch", "gpsat_glue_batch"]
+           "gpsat_smooth_batch", "gpsat_glue_batch", "gpsat_max_tile_obs"]
 
 
 class GpsatOpts(C.Structure):
@@ -86,11 +86,18 @@ def load():
     lib.gpsat_glue_batch.restype = C.c_int
     lib.gpsat_glue_batch.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    lib.gpsat_max_tile_obs.restype = C.c_int
+    lib.gpsat_max_tile_obs.argtypes = [C.c_int, C.c_int]
     lib.gpsat_last_timing.restype = C.c_int
     lib.gpsat_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     if lib.gpsat_version() != ABI_VERSION:
         raise LibraryMissing(f"ABI version mismatch: library {lib.gpsat_version()} != binding {ABI_VERSION}")
     return lib
+
+
+def max_tile_obs(dtype: str, D: int) -> int:
+    """Largest tile (observations) the kernels take for this dtype / input dimension (gpsat_max_tile_obs)."""
+    return int(get_lib().gpsat_max_tile_obs(F32 if dtype == "f32" else F64, int(D)))
 
 
 _lib = None

@@ -76,6 +76,19 @@ int gpsat_device_count(void) {
     return n;
 }
 
+int gpsat_max_tile_obs(int dtype, int D) {
+    // the largest tile whose workgroup state (coordinates, y, z, alpha, factor buffers, optimiser state) fits the
+    // 160 KiB LDS of a CU with one workgroup per CU (8-wave builds)
+    if (D < 1 || D > 3 || (dtype != GPSAT_F32 && dtype != GPSAT_F64)) return 0;
+    const bool f64 = dtype == GPSAT_F64;
+    const int bs = f64 ? 16 : 32;
+    for (int NB = 4096 / bs; NB >= 1; --NB) {
+        const size_t smem = f64 ? gpsat::shared_bytes_f64(D, NB) : gpsat::shared_bytes_w8(D, NB);
+        if (smem <= 160 * 1024) return NB * bs;
+    }
+    return 0;
+}
+
 int gpsat_create(int device_id, const gpsat_opts* opts, gpsat_handle** out) {
     if (!out) return fail(GPSAT_EINVAL, "gpsat_create: out is NULL");
     *out = nullptr;
@@ -164,8 +177,9 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
         }
         sumC = b->cov_off[T];
     }
-    if (maxN > (f64 ? 2048 : 4096))
-        return fail(GPSAT_EINVAL, "tile too large for this build (4096 observations in fp32, 2048 in fp64)");
+    if (maxN > gpsat_max_tile_obs(b->dtype, b->D))
+        return fail(GPSAT_EINVAL, "tile too large for the LDS of a CU: at most " + std::to_string(gpsat_max_tile_obs(b->dtype, b->D)) +
+                                      " observations per tile for this dtype and D (gpsat_max_tile_obs)");
     if (sumN > 0 && (!b->X || !b->y)) return fail(GPSAT_EINVAL, "X / y is NULL");
     if (sumP > 0 && (!b->Xs || !b->f_mean || !b->f_var || !b->y_var)) return fail(GPSAT_EINVAL, "prediction pointer is NULL");
     for (int t = 0; t < T; ++t)

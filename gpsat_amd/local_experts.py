@@ -63,8 +63,7 @@ from .models import HipGPRModel, LIKELIHOOD_VARIANCE_LOWER_BOUND, clamp_within
 _COMPS = {">=": np.greater_equal, ">": np.greater, "==": np.equal, "<": np.less, "<=": np.less_equal}
 PARAM_NAMES = ["lengthscales", "kernel_variance", "likelihood_variance"]
 MODEL_NAME = f"{HipGPRModel.__module__}.{HipGPRModel.__name__}"[:64]
-# largest tile the kernels take (gpsat_capi.cpp); larger tiles get an explicit error row instead of failing the batch
-MAX_OBS = {"f32": 4096, "f64": 2560}
+DTYPES = ("f32", "f64")
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -427,7 +426,7 @@ class BatchedLocalExpertOI:
                  engine=None, device_select: bool = False, dtype: str = "f32"):
         self.config = {"locations": _jsonable(expert_loc_config), "data": _jsonable(data_config),
                        "model": _jsonable(model_config), "pred_loc": _jsonable(pred_loc_config)}
-        if dtype not in MAX_OBS:
+        if dtype not in DTYPES:
             raise ValueError("dtype must be 'f32' (default) or 'f64' (the reference's precision)")
         self.dtype = dtype
         # ---- data (local_experts.py:266-290)
@@ -642,11 +641,14 @@ class BatchedLocalExpertOI:
         # item kinds: 0 skipped silently (no prediction locations, local_experts.py:962-965), 1 stub row
         # (N < min_obs, :988-1012), 2 tile, 3 error row (tile larger than the kernels take)
         kind = np.full(len(ex), 2, dtype=np.int8)
-        kind[n_obs > MAX_OBS[self.dtype]] = 3
+        # largest tile the kernels take (gpsat_max_tile_obs): larger ones get an explicit error row instead of failing
+        # the whole batch
+        max_obs = L.max_tile_obs(self.dtype, D)
+        kind[n_obs > max_obs] = 3
         kind[n_obs < min_obs] = 1
         kind[n_pred == 0] = 0
         if (kind == 3).any():
-            warnings.warn(f"{int((kind == 3).sum())} expert locations select more than {MAX_OBS[self.dtype]} "
+            warnings.warn(f"{int((kind == 3).sum())} expert locations select more than {max_obs} "
                           f"observations: not run (error row in run_details)")
         is_repl = (n_obs < self.replacement_threshold) if self.replacement_threshold is not None \
             else np.zeros(len(ex), dtype=bool)                      # local_experts.py:1021-1041

@@ -152,6 +152,14 @@ const char *gpsat_last_error(void);
 int gpsat_device_count(void);
 
 /*
+ * Largest number of observations one tile may hold for `dtype` (GPSAT_F32 / GPSAT_F64) and input dimension D: the
+ * tile's coordinates, observations and solve vectors stay in the 160 KiB LDS of its CU for the whole fit (D = 3:
+ * 2,800 in fp64 -- the reference's published N = 2,500 fp64 fit, docs/notebooks/using_gpus.ipynb:77,165, fits -- and
+ * 3,168 in fp32).  A batch holding a larger tile is refused with GPSAT_EINVAL.  0 for unsupported arguments.  ABI >= 3.
+ */
+int gpsat_max_tile_obs(int dtype, int D);
+
+/*
  * Create an engine bound to one GPU.  Replaces model construction-time device discovery
  * (BaseGPRModel._get_device_names, base_model.py:279-300).  `opts` may be NULL.
  */
