@@ -4,14 +4,25 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch of synthetic expert tiles resident in HBM:
-for every tile, L-BFGS fit of the 5 hyper-parameters (max_iter optimiser iterations), the objective
-at the optimum, and the predictive mean / variances at P points -- all inside ONE persistent
-gfx950 kernel launch per step (gpsat_fit_predict_batch).  Workload at N=1 = BASELINE.json
-configs[1]: 4,096 tiles, 500 obs/tile, RBF, 3-D inputs, fp32, 20 optimiser steps, P = 500.
-Tiles shard embarrassingly: every rank owns --tiles tiles (weak scaling), no data-path collective;
-one RCCL all_gather of per-tile hyper-parameters + predictions closes each step when N > 1.
-Prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path over one batch of synthetic expert tiles resident in HBM: for every tile, L-BFGS
+fit of the 5 hyper-parameters (max_iter optimiser iterations), the objective at the optimum, and the predictive mean /
+variances at P points -- all inside ONE persistent gfx950 kernel launch per step (gpsat_fit_predict_batch).
+
+Workloads (``--workload``):
+  configs1 (default)  BASELINE.json configs[1], the metric's workload: 4,096 tiles x 500 obs, RBF, 3-D, fp32, 20
+                      optimiser steps, P = 500.  Weak scaling: every rank owns --tiles tiles, no data-path collective,
+                      one RCCL all_gather of per-tile hyper-parameters + predictions closes each step when N > 1.
+  configs2            BASELINE.json configs[2]: ragged N in {128..2048}, Matern-3/2, fp32.
+  configs4            BASELINE.json configs[4] per GPU: fp64, N = 2000, predict-only with given hyper-parameters.
+  --global-tiles G    BASELINE.json configs[3]: ONE global list of G tiles (N = 500, RBF), split over the ranks by the
+                      LPT partition (sharding.partition_tiles), each rank runs its shard, one gather(v) of
+                      hyper-parameters + predictions to rank 0 in the reference's tile order.  Strong scaling.
+``--exact-iters`` switches the optimiser's early stopping off (ftol = gtol = off): every tile runs exactly max_iter
+iterations unless its line search fails; the CPU baseline then runs SciPy with ftol = gtol = 0 on matched work.
+
+Prints ONE JSON line on rank 0.  ``value`` = whole-job tiles/s with inputs resident in HBM; ``host_to_host_ms`` is the
+same step timed from packed host arrays to outputs on the host (SURVEY.md 8(d)'s definition, PCIe included) -- context,
+never ``value``.
 """
 import argparse
 import json
@@ -25,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
+PEAK_F64_MFMA_TFLOPS = 78.6
 
 
 def f_eval(N, D):     # one objective+gradient evaluation
@@ -39,167 +51,219 @@ def f_pred(N, P, D):
     return N * N * P + 2 * N * P + (3 * D + 6) * N * P / 2 + P * N
 
 
-def measured_traffic(a, T, N, P, D):
-    """HBM bytes per launch measured with rocprofv3 PMC passes (profiles/traffic.json), only when the
-    workload is the one it was measured on; otherwise null."""
+def measured_traffic(key, sig):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json: FETCH_SIZE doubled per
+    the gfx950 rule + WRITE_SIZE, separate --pmc passes of this same command), only when the workload signature
+    matches the one it was measured on; otherwise null."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        w = t["workload"]
-        same = (w["tiles_per_gpu"], w["obs_per_tile"], w["pred_per_tile"], w["dim"], w["kernel"], w["optimiser"],
-                w["max_iter"]) == (T, N, P, D, a.kernel, a.optimiser, a.max_iter)
-        return float(t["hbm_bytes_per_launch"]) if same else None
+        e = t[key] if key in t else (t if key == "configs1" and "workload" in t else None)
+        if e is None:
+            return None, None
+        w = e["workload"]
+        same = all(sig.get(k) == v for k, v in w.items())
+        return (float(e["hbm_bytes_per_launch"]), e.get("source")) if same else (None, None)
     except Exception:
-        return None
+        return None, None
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if "model name" in line:
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+# ----------------------------------------------------------------------------------------------------------
+# synthetic tiles (SURVEY.md section 8d), generated in parallel on the host BEFORE the GPU is initialised
+# ----------------------------------------------------------------------------------------------------------
 def _gen_tile(args):
     from gpsat_amd import synthetic as syn
     seed, N, P, D, kid = args
     return syn.make_tile(seed, N, P, D, kid)
 
 
-def make_tiles(T, N, P, D, kid, base_seed, workers):
-    """Synthetic tiles, generated in parallel on the host."""
+def gen_tiles(jobs, workers):
     from multiprocessing import get_context
-    jobs = [(base_seed + t, N, P, D, kid) for t in range(T)]
-    if workers > 1:
+    if workers > 1 and len(jobs) > 1:
         with get_context("fork").Pool(workers) as pool:
-            res = pool.map(_gen_tile, jobs, chunksize=max(1, T // (workers * 8)))
+            return pool.map(_gen_tile, jobs, chunksize=max(1, len(jobs) // (workers * 8)))
+    return [_gen_tile(j) for j in jobs]
+
+
+def build_workload(a, rank, world, workers):
+    """Returns the rank's packed batch + metadata.  Prototype tiles are generated once and replicated where the tile
+    count is large (the arithmetic does not depend on the values; replicas are made distinct by scaling y)."""
+    from gpsat_amd import _lib as L
+    from gpsat_amd import synthetic as syn
+    D, P = a.dim, a.npred
+    w = dict(D=D, P=P, peak=PEAK_F32_MFMA_TFLOPS, dtype="f32", np_dt=np.float32, scaling="weak", global_T=None)
+    if a.global_tiles > 0:
+        G, N, kid = a.global_tiles, a.nobs, L.KERNEL_IDS[a.kernel]
+        from gpsat_amd import sharding
+        parts = sharding.partition_tiles(np.full(G, N), np.full(G, P), world, a.max_iter)
+        mine = parts[rank]
+        NPROTO = min(G, 2048)
+        proto = gen_tiles([(9_000_000 + j, N, P, D, kid) for j in range(NPROTO)], workers)
+        pX = np.stack([p[0] for p in proto]).astype(np.float32)
+        py = np.stack([p[1] for p in proto])
+        pXs = np.stack([p[2] for p in proto]).astype(np.float32)
+        j, rep = mine % NPROTO, mine // NPROTO
+        X = pX[j].reshape(-1, D)
+        y = (py[j] * (1.0 + 0.01 * rep)[:, None]).reshape(-1).astype(np.float32)
+        Xs = pXs[j].reshape(-1, D)
+        T = len(mine)
+        lo, hi = syn.default_bounds(T, D)
+        w.update(name=f"BASELINE.json configs[3]: ONE list of {G} synthetic tiles, N={N}, RBF, 3D inputs, fp32, LPT-sharded",
+                 key="configs3", T=T, Ns=np.full(T, N), kid=kid, kernel=a.kernel, optimiser=a.optimiser, max_iter=a.max_iter,
+                 X=X, y=y, Xs=Xs, theta0=np.ones((T, D + 2)), lo=lo, hi=hi, scaling="strong", global_T=G, mine=mine,
+                 data="synthetic (2048 prototype tiles, replicas distinct by scaled observations)")
+    elif a.workload == "configs1":
+        T, N, kid = a.tiles, a.nobs, L.KERNEL_IDS[a.kernel]
+        res = gen_tiles([(1_000_000 * rank + t, N, P, D, kid) for t in range(T)], workers)
+        lo, hi = syn.default_bounds(T, D)
+        w.update(name="BASELINE.json configs[1]: synthetic tiles, RBF, 3D inputs, fp32", key="configs1", T=T, Ns=np.full(T, N),
+                 kid=kid, kernel=a.kernel, optimiser=a.optimiser, max_iter=a.max_iter,
+                 X=np.concatenate([r[0] for r in res]).astype(np.float32), y=np.concatenate([r[1] for r in res]).astype(np.float32),
+                 Xs=np.concatenate([r[2] for r in res]).astype(np.float32), theta0=np.ones((T, D + 2)), lo=lo, hi=hi,
+                 data="synthetic")
+    elif a.workload == "configs2":
+        T = a.tiles if a.tiles != 4096 else 1024
+        kid = 2
+        sizes = [128, 256, 384, 512, 768, 1024, 1536, 2048]
+        Ns = np.random.default_rng(rank).choice(sizes, T)
+        protos = gen_tiles([(100 + 10 * i + j, n, P, D, kid) for i, n in enumerate(sizes) for j in range(2)], workers)
+        proto = {n: protos[2 * i:2 * i + 2] for i, n in enumerate(sizes)}
+        parts = [proto[int(n)][t % 2] for t, n in enumerate(Ns)]
+        lo, hi = syn.default_bounds(T, D)
+        w.update(name="BASELINE.json configs[2]: ragged tiles N in {128..2048}, Matern-3/2, 3D inputs, fp32", key="configs2",
+                 T=T, Ns=Ns, kid=kid, kernel="Matern32", optimiser="lbfgs", max_iter=a.max_iter,
+                 X=np.concatenate([p[0] for p in parts]).astype(np.float32), y=np.concatenate([p[1] for p in parts]).astype(np.float32),
+                 Xs=np.concatenate([p[2] for p in parts]).astype(np.float32), theta0=np.ones((T, D + 2)), lo=lo, hi=hi,
+                 data="synthetic (two prototype tiles per size class, replicated)")
     else:
-        res = [_gen_tile(j) for j in jobs]
-    X = np.concatenate([r[0] for r in res]).astype(np.float32)
-    y = np.concatenate([r[1] for r in res]).astype(np.float32)
-    Xs = np.concatenate([r[2] for r in res]).astype(np.float32)
-    obs_off = np.arange(T + 1, dtype=np.int64) * N
-    pred_off = np.arange(T + 1, dtype=np.int64) * P
-    return X, y, Xs, obs_off, pred_off
+        T = a.tiles if a.tiles != 4096 else 1024
+        kid = 0
+        protos = gen_tiles([(1 + j, 2000, P, D, kid) for j in range(8)], workers)
+        parts = [protos[t % 8] for t in range(T)]
+        w.update(name="BASELINE.json configs[4] per GPU: fp64, N=2000, predict-only with given hyper-parameters", key="configs4",
+                 T=T, Ns=np.full(T, 2000), kid=kid, kernel="RBF", optimiser="none", max_iter=0, dtype="f64", np_dt=np.float64,
+                 peak=PEAK_F64_MFMA_TFLOPS,
+                 X=np.concatenate([p[0] for p in parts]), y=np.concatenate([p[1] for p in parts]),
+                 Xs=np.concatenate([p[2] for p in parts]),
+                 theta0=np.stack([p[3] for p in parts]),      # the generating parameters stand in for the smoothed ones
+                 lo=None, hi=None, data="synthetic (eight prototype tiles, replicated)")
+    w["obs_off"] = np.concatenate([[0], np.cumsum(w["Ns"])]).astype(np.int64)
+    w["pred_off"] = np.arange(w["T"] + 1, dtype=np.int64) * P
+    return w
+
+
+# ----------------------------------------------------------------------------------------------------------
+# cpu_baseline leg: the fp64 oracle (a port of the reference's algorithm) on a bounded sample of the same tiles
+# ----------------------------------------------------------------------------------------------------------
+def _cpu_warm(_):
+    import scipy.linalg  # noqa: F401
+    from oracle import gp_oracle  # noqa: F401
+    return 0
 
 
 def _cpu_tile(args):
-    """cpu_baseline leg: the fp64 oracle (a port of the reference's algorithm) on one tile."""
-    os.environ.setdefault("OMP_NUM_THREADS", "1")
-    try:
-        from threadpoolctl import threadpool_limits
-        ctx = threadpool_limits(1)
-    except Exception:
-        ctx = None
+    X, y, Xs, D, kid, max_iter, lo, hi, theta0, optimise, exact, nthreads = args
+    from threadpoolctl import threadpool_limits
     from oracle import gp_oracle as go
-    X, y, Xs, D, kid, max_iter, lo, hi = args
-    t0 = time.perf_counter()
-    o = go.fit_predict_batch(kid, D, np.array([0, len(y)]), X, y, np.array([0, len(Xs)]), Xs,
-                             np.ones((1, D + 2)), lo[None], hi[None], np.ones(D + 2, bool), max_iter=max_iter)
-    dt = time.perf_counter() - t0
-    return dt, int(o["n_eval"][0])
+    with threadpool_limits(nthreads):
+        t0 = time.perf_counter()
+        m = go.OracleGPR(X, y, kernel={0: "RBF", 1: "Matern12", 2: "Matern32", 3: "Matern52"}[kid])
+        m.theta = np.array(theta0, dtype=np.float64)
+        if lo is not None:
+            box = np.isfinite(lo) & np.isfinite(hi)
+            m.lo, m.hi = np.where(box, lo, -np.inf), np.where(box, hi, np.inf)
+            m.shift = np.where(box, 0.0, m.shift)
+        nit = 0
+        if optimise:
+            # SciPy defaults (what the reference runs), or both stopping tests off for matched work with --exact-iters
+            opts = dict(maxiter=max_iter, ftol=0.0, gtol=0.0) if exact else dict(maxiter=max_iter)
+            D_ = X.shape[1]
+            u_all = go.u_from_theta(m.theta, m.lo, m.hi, m.shift)
+            cnt = [0]
 
-
-def cpu_baseline(X, y, Xs, N, P, D, kid, max_iter, n_tiles, workers):
-    from multiprocessing import get_context
-    from gpsat_amd import synthetic as syn
-    lo, hi = syn.default_bounds(1, D)
-    jobs = [(X[t * N:(t + 1) * N].astype(np.float64), y[t * N:(t + 1) * N].astype(np.float64),
-             Xs[t * P:(t + 1) * P].astype(np.float64), D, kid, max_iter, lo[0], hi[0]) for t in range(n_tiles)]
-    t0 = time.perf_counter()
-    with get_context("fork").Pool(workers) as pool:
-        res = pool.map(_cpu_tile, jobs, chunksize=1)
-    wall = time.perf_counter() - t0
-    return n_tiles / wall, float(np.mean([r[1] for r in res])), wall
-
-
-def other_workload(a):
-    """The other single-GPU shapes of BASELINE.json as non-default bench lines (same timing protocol; prototype tiles
-    per size class are generated once and replicated -- the arithmetic does not depend on the values)."""
-    from gpsat_amd import synthetic as syn
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    D, P = 3, 500
-    if a.workload == "configs2":
-        T = a.tiles if a.tiles != 4096 else 1024
-        kid, kernel, dtype, np_dt, optimiser, max_iter = 2, "Matern32", "f32", np.float32, "lbfgs", a.max_iter
-        sizes = [128, 256, 384, 512, 768, 1024, 1536, 2048]
-        Ns = np.random.default_rng(rank).choice(sizes, T)
-        proto = {n: [syn.make_tile(100 + 10 * i + j, n, P, D, kid) for j in range(2)] for i, n in enumerate(sizes)}
-        parts = [proto[int(n)][t % 2] for t, n in enumerate(Ns)]
-        theta0 = np.ones((T, D + 2))
-        lo, hi = syn.default_bounds(T, D)
-        name = "BASELINE.json configs[2]: ragged tiles N in {128..2048}, Matern-3/2, 3D inputs, fp32"
-        peak = PEAK_F32_MFMA_TFLOPS
-    else:
-        T = a.tiles if a.tiles != 4096 else 1024
-        kid, kernel, dtype, np_dt, optimiser, max_iter = 0, "RBF", "f64", np.float64, "none", 0
-        Ns = np.full(T, 2000)
-        proto = [syn.make_tile(1 + j, 2000, P, D, kid) for j in range(8)]
-        parts = [proto[t % 8] for t in range(T)]
-        theta0 = np.stack([pp[3] for pp in parts])          # the generating hyper-parameters stand in for the smoothed ones
-        lo = hi = None
-        name = "BASELINE.json configs[4] per GPU: fp64, N=2000, predict-only with given hyper-parameters"
-        peak = 78.6                                         # fp64 MFMA, MI355X_MICROARCH.md
-    X = np.concatenate([pp[0] for pp in parts]).astype(np_dt)
-    y = np.concatenate([pp[1] for pp in parts]).astype(np_dt)
-    Xs = np.concatenate([pp[2] for pp in parts]).astype(np_dt)
-    obs_off = np.concatenate([[0], np.cumsum(Ns)])
-    pred_off = np.arange(T + 1) * P
-
-    import torch
-    import torch.distributed as dist
-    from gpsat_amd.engine import Engine
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
-    if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-    dX, dy, dXs = (torch.from_numpy(v).to(dev) for v in (X, y, Xs))
-    eng = Engine(local_rank)
-    kw = dict(D=D, obs_off=obs_off, X=dX, y=dy, pred_off=pred_off, Xs=dXs, theta0=theta0, kernel=kernel, optimiser=optimiser,
-              max_iter=max_iter, dtype=dtype)
-    if lo is not None:
-        kw.update(lo=lo, hi=hi)
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        eng.fit_predict_batch(**kw)
-    barrier()
-    t0 = time.perf_counter()
-    kms = []
-    for _ in range(a.steps):
-        r = eng.fit_predict_batch(**kw)
-        kms.append(r.kernel_ms)
-    barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    if rank == 0:
-        Nf = Ns.astype(np.float64)
-        if a.workload == "configs2":
-            flops = float((r.n_eval * f_eval(Nf, D) + f_pred(Nf, P, D)).sum())
+            def fun(u):
+                th = go.theta_from_u(u, m.lo, m.hi, m.shift)
+                f, g = go.nll_and_grad(kid, X, y, th)
+                cnt[0] += 1
+                if not np.isfinite(f):
+                    return 1e300, np.zeros(D_ + 2)
+                return f, g * go.dtheta_du(th, m.lo, m.hi, m.shift)
+            from scipy.optimize import minimize
+            res = minimize(fun, u_all, jac=True, method="L-BFGS-B", options=opts)
+            m.theta = go.theta_from_u(res.x, m.lo, m.hi, m.shift)
+            m.n_eval, nit = cnt[0], int(res.nit)
         else:
-            flops = float((f_nll(Nf, D) + f_pred(Nf, P, D)).sum())
-        k_ms = float(np.mean(kms))
-        ach = flops / (k_ms * 1e-3) / 1e12
-        print(json.dumps({
-            "metric": "local-expert tiles/sec (fit+predict)", "value": round(T * world * a.steps / dt, 2), "unit": "tiles/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
-            "data": "synthetic (prototype tiles per size class, replicated)",
-            "config": {"workload": name, "tiles_per_gpu": int(T), "mean_obs_per_tile": float(Nf.mean()), "pred_per_tile": P,
-                       "dim": D, "kernel": kernel, "optimiser": optimiser, "max_iter": max_iter,
-                       "evals_per_tile": round(float(r.n_eval.mean()), 2), "failed_tiles": int(np.sum((r.status == 2) | (r.status == 3))),
-                       "parallelism": f"tile-sharded x{world}", "device": eng.device_name},
-            "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4), "traffic": None, "kernel_ms": round(k_ms, 3), "flops_per_launch": flops},
-        }), flush=True)
-    if use_dist:
-        dist.destroy_process_group()
-    eng.close()
+            m.n_eval = 0
+        m.get_objective_function_value()
+        if len(Xs):
+            m.predict(Xs, apply_scale=False)
+        return time.perf_counter() - t0, int(m.n_eval), nit
+
+
+def cpu_baseline(w, a, workers):
+    """Bounded sample (about 10-30 s of CPU work in all).  Layouts: one single-threaded process per core, and one process
+    with all-thread BLAS; modes: the GPU run's iteration budget, and SciPy run to its default convergence."""
+    from multiprocessing import get_context
+    D, P = w["D"], w["P"]
+    optimise = w["optimiser"] != "none"
+
+    def jobs(n, max_iter, exact, nthreads):
+        out = []
+        for t in range(min(n, w["T"])):
+            o0, o1 = w["obs_off"][t], w["obs_off"][t + 1]
+            out.append((w["X"][o0:o1].astype(np.float64), w["y"][o0:o1].astype(np.float64),
+                        w["Xs"][t * P:(t + 1) * P].astype(np.float64), D, w["kid"], max_iter,
+                        None if w["lo"] is None else w["lo"][t], None if w["hi"] is None else w["hi"][t], w["theta0"][t],
+                        optimise, exact, nthreads))
+        return out
+    mean_n3 = float(np.mean(w["Ns"].astype(np.float64) ** 3))
+    scale = (500.0 ** 3) / mean_n3                                        # sample sizes quoted for N = 500 tiles
+    n_main = a.cpu_tiles if a.cpu_tiles > 0 else max(workers, int(256 * min(1.0, scale * (1.0 if optimise else 8.0))))
+    modes = {}
+    with get_context("fork").Pool(workers) as pool:
+        pool.map(_cpu_warm, range(workers * 2))                             # pool start-up and imports are not timed
+        t0 = time.perf_counter()
+        res = pool.map(_cpu_tile, jobs(n_main, w["max_iter"], a.exact_iters, 1), chunksize=1)
+        wall = time.perf_counter() - t0
+        n_done = len(res)
+        modes["budget_per_core"] = dict(tiles_per_s=round(n_done / wall, 3), tiles=n_done, wall_s=round(wall, 2),
+                                        evals_per_tile=round(float(np.mean([r[1] for r in res])), 2),
+                                        iters_per_tile=round(float(np.mean([r[2] for r in res])), 2),
+                                        layout=f"{workers} single-threaded processes")
+        if optimise and not a.exact_iters:
+            t0 = time.perf_counter()
+            res_c = pool.map(_cpu_tile, jobs(max(workers, n_main // 4), 10_000, False, 1), chunksize=1)
+            wall_c = time.perf_counter() - t0
+            modes["converged_per_core"] = dict(tiles_per_s=round(len(res_c) / wall_c, 3), tiles=len(res_c), wall_s=round(wall_c, 2),
+                                               evals_per_tile=round(float(np.mean([r[1] for r in res_c])), 2),
+                                               iters_per_tile=round(float(np.mean([r[2] for r in res_c])), 2),
+                                               layout=f"{workers} single-threaded processes, SciPy default convergence (maxiter 10000)")
+    # all-thread BLAS, one process (after the pool is gone: BLAS threads and fork do not mix)
+    n_blas = max(2, n_main // 16)
+    t0 = time.perf_counter()
+    res_b = [_cpu_tile(j) for j in jobs(n_blas, w["max_iter"], a.exact_iters, None)]
+    wall_b = time.perf_counter() - t0
+    modes["budget_allthread_blas"] = dict(tiles_per_s=round(len(res_b) / wall_b, 3), tiles=len(res_b), wall_s=round(wall_b, 2),
+                                          evals_per_tile=round(float(np.mean([r[1] for r in res_b])), 2),
+                                          layout=f"one process, BLAS on all {os.cpu_count()} threads")
+    best = max(("budget_per_core", "budget_allthread_blas"), key=lambda k: modes[k]["tiles_per_s"])
+    m = modes[best]
+    what = (f"L-BFGS-B maxiter={w['max_iter']}" + (", ftol=gtol=0" if a.exact_iters else ", SciPy default tolerances")) if optimise \
+        else "objective + predict only"
+    return {"value": m["tiles_per_s"], "unit": "tiles/s", "cores": workers if best == "budget_per_core" else os.cpu_count(),
+            "kind": "port", "cpu_model": cpu_model(), "host_threads": os.cpu_count(),
+            "sample": f"{m['tiles']} of the same tiles, fp64 NumPy/SciPy oracle ({what}, {m['evals_per_tile']} evals/tile, "
+                      f"predict P={P}), {m['layout']}, {m['wall_s']} s wall (pool start-up excluded); faster of the two layouts",
+            "modes": modes}
 
 
 def main():
@@ -208,52 +272,40 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tiles", type=int, default=4096, help="tiles per GPU (weak scaling)")
+    ap.add_argument("--global-tiles", type=int, default=0, help="ONE global tile list split over the ranks (strong scaling, configs[3])")
     ap.add_argument("--nobs", type=int, default=500)
     ap.add_argument("--npred", type=int, default=500)
     ap.add_argument("--dim", type=int, default=3)
     ap.add_argument("--kernel", default="RBF")
     ap.add_argument("--optimiser", default="lbfgs")
     ap.add_argument("--max-iter", type=int, default=20)
-    ap.add_argument("--cpu-tiles", type=int, default=-1, help="tiles in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--exact-iters", action="store_true", help="early stopping off: exactly max_iter iterations per tile")
+    ap.add_argument("--cpu-tiles", type=int, default=-1, help="tiles in the CPU baseline sample (0 = skip, -1 = auto)")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the host-to-host timing")
     ap.add_argument("--wg-per-cu", type=int, default=0)
     ap.add_argument("--workers", type=int, default=0, help="host processes for data generation / CPU baseline "
                     "(0 = auto; use 1 under rocprofv3 --pmc: no fork beside the profiler)")
-    ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs4"],
-                    help="BASELINE.json configs[i]: 1 = the metric's workload (default); 2 = ragged N in {128..2048}, "
-                         "Matern-3/2, fp32; 4 = fp64, N = 2000, predict-only with given hyper-parameters")
+    ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs4"])
     a = ap.parse_args()
-    if a.workload != "configs1":
-        return other_workload(a)
-
-    from gpsat_amd import _lib as L
-    from gpsat_amd import synthetic as syn
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world and world == 1 and a.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-
-    T, N, P, D = a.tiles, a.nobs, a.npred, a.dim
-    kid = L.KERNEL_IDS[a.kernel]
-    H = D + 2
     ncpu = os.cpu_count() or 1
     workers = a.workers if a.workers > 0 else max(1, min(16, ncpu // max(1, min(world, 8))))
+
     # ---- host-side work that forks worker processes happens BEFORE the GPU / RCCL are initialised
-    X, y, Xs, obs_off, pred_off = make_tiles(T, N, P, D, kid, base_seed=1_000_000 * rank, workers=workers)
+    w = build_workload(a, rank, world, workers)
     cpu = None
-    n_cpu_tiles = a.cpu_tiles if a.cpu_tiles >= 0 else (2 * workers if world == 1 else 0)
-    if rank == 0 and n_cpu_tiles > 0:
-        v, e_cpu, wall = cpu_baseline(X, y, Xs, N, P, D, kid, a.max_iter, n_cpu_tiles, workers)
-        cpu = {"value": round(v, 3), "unit": "tiles/s", "cores": workers, "kind": "port",
-               "sample": f"{n_cpu_tiles} of the same tiles, fp64 NumPy/SciPy oracle "
-                         f"(L-BFGS-B maxiter={a.max_iter}, {e_cpu:.1f} evals/tile, predict P={P}), "
-                         f"one single-threaded process per core, {wall:.1f}s wall"}
+    if rank == 0 and world == 1 and a.cpu_tiles != 0 and workers > 1:
+        cpu = cpu_baseline(w, a, workers)
 
     import torch
     import torch.distributed as dist
+    from gpsat_amd import sharding
     from gpsat_amd.engine import Engine
-    from gpsat_amd.sharding import all_gather_equal
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
@@ -264,23 +316,31 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    dX, dy, dXs = (torch.from_numpy(v).to(dev) for v in (X, y, Xs))
-    fm = torch.empty(T * P, dtype=torch.float32, device=dev)
-    fv = torch.empty_like(fm)
-    yv = torch.empty_like(fm)
-    theta0 = np.ones((T, H))
-    lo, hi = syn.default_bounds(T, D)
+    T, D, P = w["T"], w["D"], w["P"]
+    t_dt = torch.float32 if w["dtype"] == "f32" else torch.float64
+    dX, dy, dXs = (torch.from_numpy(np.ascontiguousarray(v, dtype=w["np_dt"])).to(dev) for v in (w["X"], w["y"], w["Xs"]))
+    fm = torch.empty(max(T * P, 1), dtype=t_dt, device=dev)
+    fv, yv = torch.empty_like(fm), torch.empty_like(fm)
     eng = Engine(local_rank, workgroups_per_cu=a.wg_per_cu)
+    kw = dict(D=D, obs_off=w["obs_off"], pred_off=w["pred_off"], theta0=w["theta0"], kernel=w["kernel"], optimiser=w["optimiser"],
+              max_iter=w["max_iter"], dtype=w["dtype"])
+    if w["lo"] is not None:
+        kw.update(lo=w["lo"], hi=w["hi"])
+    if a.exact_iters:
+        kw.update(ftol=-1.0, gtol=-1.0)
 
     def step():
-        r = eng.fit_predict_batch(D=D, obs_off=obs_off, X=dX, y=dy, pred_off=pred_off, Xs=dXs, theta0=theta0,
-                                  lo=lo, hi=hi, kernel=a.kernel, optimiser=a.optimiser, max_iter=a.max_iter,
-                                  out=(fm, fv, yv))
+        r = eng.fit_predict_batch(X=dX, y=dy, Xs=dXs, out=(fm, fv, yv), **kw)
         if use_dist:
-            # final gather of per-tile hyper-parameters + predictions (the only collective of the path)
             fixed = torch.from_numpy(np.concatenate([r.theta, r.nll[:, None], r.status[:, None].astype(np.float64),
-                                                     r.n_eval[:, None].astype(np.float64)], axis=1)).to(dev)
-            all_gather_equal(fixed, torch.stack([fm, fv, yv], dim=1), world)
+                                                     r.n_eval[:, None].astype(np.float64), r.n_iter[:, None].astype(np.float64)],
+                                                    axis=1)).to(dev)
+            preds = torch.stack([fm[:T * P], fv[:T * P], yv[:T * P]], dim=1)
+            if w["scaling"] == "strong":
+                # the only exchange the path has: gather(v) of per-tile results into the reference's tile order on rank 0
+                sharding.gather_results(fixed, preds, np.full(T, P), w["mine"], world, rank, device=dev, total=w["global_T"])
+            else:
+                sharding.all_gather_equal(fixed, preds, world)
         return r
 
     def barrier():
@@ -292,12 +352,10 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    kernel_ms, n_eval_sum, statuses = [], 0, None
+    kernel_ms = []
     for _ in range(a.steps):
         r = step()
         kernel_ms.append(r.kernel_ms)
-        n_eval_sum = int(r.n_eval.sum())
-        statuses = r.status
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -305,29 +363,51 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # ---- the same step from packed host arrays to outputs on the host; context, never `value`
+    host_ms = None
+    if rank == 0 and not a.no_host_leg:
+        hX, hy, hXs = (np.ascontiguousarray(v, dtype=w["np_dt"]) for v in (w["X"], w["y"], w["Xs"]))
+        eng.fit_predict_batch(X=hX, y=hy, Xs=hXs, **kw)
+        th = time.perf_counter()
+        eng.fit_predict_batch(X=hX, y=hy, Xs=hXs, **kw)
+        host_ms = (time.perf_counter() - th) * 1e3
+
     if rank == 0:
-        tiles_total = T * world * a.steps
-        value = tiles_total / dt
-        E = n_eval_sum / T                                    # evaluations per tile actually performed
-        flops_launch = T * (E * f_eval(N, D) + f_pred(N, P, D))
+        Nf = w["Ns"].astype(np.float64)
+        n_eval = r.n_eval.astype(np.float64)
+        if w["optimiser"] == "none":
+            flops_launch = float((f_nll(Nf, D) + f_pred(Nf, P, D)).sum())
+        else:
+            flops_launch = float((n_eval * f_eval(Nf, D) + f_pred(Nf, P, D)).sum())
         k_ms = float(np.mean(kernel_ms))
         achieved = flops_launch / (k_ms * 1e-3) / 1e12
+        total_tiles = (w["global_T"] if w["scaling"] == "strong" else T * world) * a.steps
+        sig = dict(tiles_per_gpu=int(T), obs_per_tile=float(Nf.mean()), pred_per_tile=P, dim=D, kernel=w["kernel"],
+                   optimiser=w["optimiser"], max_iter=w["max_iter"], exact_iters=bool(a.exact_iters))
+        traffic, traffic_src = measured_traffic(w["key"], sig)
+        st = r.status
         out = {
-            "metric": "local-expert tiles/sec (fit+predict)", "value": round(value, 2), "unit": "tiles/s",
+            "metric": "local-expert tiles/sec (fit+predict)", "value": round(total_tiles / dt, 2), "unit": "tiles/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: synthetic tiles, RBF, 3D inputs, fp32",
-                       "tiles_per_gpu": T, "obs_per_tile": N, "pred_per_tile": P, "dim": D, "kernel": a.kernel,
-                       "optimiser": a.optimiser, "max_iter": a.max_iter, "evals_per_tile": round(E, 2),
-                       "converged_frac": round(float(np.mean(statuses == 0)), 3),
-                       "failed_tiles": int(np.sum(statuses >= 2)),
-                       "parallelism": f"tile-sharded x{world}", "device": eng.device_name},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic": measured_traffic(a, T, N, P, D),
-                         "kernel": f"gp_tile_kernel<{D}, {kid}>", "kernel_ms": round(k_ms, 3),
-                         "flops_per_launch": flops_launch},
+            "higher_is_better": True, "scaling": w["scaling"], "vs_baseline": None, "dtype": w["dtype"], "data": w["data"],
+            "host_to_host_ms": None if host_ms is None else round(host_ms, 3),
+            "config": {"workload": w["name"], "tiles_per_gpu": int(T), "obs_per_tile": float(Nf.mean()), "pred_per_tile": P,
+                       "dim": D, "kernel": w["kernel"], "optimiser": w["optimiser"], "max_iter": w["max_iter"],
+                       "early_stopping": "off (exactly max_iter iterations)" if a.exact_iters else "ftol/gtol defaults",
+                       "evals_per_tile": round(float(n_eval.mean()), 2),
+                       "iters_per_tile": round(float(r.n_iter.mean()), 2),
+                       "converged_frac": round(float(np.mean(st == 0)), 3), "max_iter_frac": round(float(np.mean(st == 1)), 3),
+                       "ls_failed_frac": round(float(np.mean(st == 6)), 4),
+                       "failed_tiles": int(np.sum((st == 2) | (st == 3))),
+                       "parallelism": f"tile-sharded x{world}" + (" (LPT over one global list, gather to rank 0)" if w["scaling"] == "strong" else ""),
+                       "device": eng.device_name},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": w["peak"], "unit": "TFLOP/s",
+                         "frac": round(achieved / w["peak"], 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": f"gp_tile_kernel<{D}, {w['kid']}>" + (" (fp64)" if w["dtype"] == "f64" else ""),
+                         "kernel_ms": round(k_ms, 3), "flops_per_launch": flops_launch},
         }
+        if w["global_T"]:
+            out["config"]["global_tiles"] = int(w["global_T"])
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

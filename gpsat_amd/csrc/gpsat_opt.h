@@ -312,11 +312,19 @@ static __device__ __noinline__ void opt_advance(Shared* sh, int H, const OptCfg&
                 opt_start_iteration(sh, H, o);
                 return;
             }
-            // Line search failed (no step satisfying the strong Wolfe conditions within max_ls evaluations).  As L-BFGS-B
-            // does (lnsrlb info != 0): with a non-empty history, discard it and restart once from steepest descent at the
-            // accepted point (the restart is not an iteration); with an empty history give up -- SciPy reports
-            // ABNORMAL_TERMINATION_IN_LNSRCH, success=False, hence a status of its own.  The best sufficient-decrease
-            // point seen by the failed search (if any) is kept rather than thrown away.
+            // Line search failed (no step satisfying the strong Wolfe conditions within max_ls evaluations).
+            //  * The last accepted step had already brought the decrease to within 100 x the ftol threshold: the objective
+            //    is being resolved at the noise floor of the arithmetic (fp32: rounding ~ cond(K) eps N), a further
+            //    decrease cannot be told from noise.  That is the finite-precision form of the ftol test: converged.
+            //  * Otherwise as L-BFGS-B (mainlb, info != 0): with a non-empty history, discard it and restart once from
+            //    steepest descent at the accepted point (the restart is not an iteration); with an empty history give up
+            //    -- SciPy reports ABNORMAL_TERMINATION_IN_LNSRCH, success=False, hence a status of its own.  The best
+            //    sufficient-decrease point seen by the failed search (if any) is kept rather than thrown away.
+            if (sh->iter > 0 && o.ftol > 0.0 && sh->last_dec <= 1e2 * o.ftol * fmax(fabs(sh->f), 1.0)) {
+                sh->status = ST_CONVERGED;
+                opt_finish(sh, H, o, false);
+                return;
+            }
             if (sh->hist_n > 0) {
                 sh->hist_n = 0;
                 opt_start_iteration(sh, H, o);

@@ -7,7 +7,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT/summary
 cd /tmp && export TMPDIR=/tmp
-B="$ROOT/bench.py --cpu-tiles 0 --workers 1"
+B="$ROOT/bench.py --cpu-tiles 0 --workers 1 --no-host-leg $BENCH_ARGS"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $B --steps 3 --warmup 1 > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 echo stats done
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -- python3 $B --steps 1 --warmup 0 > $OUT/fetch.log 2>&1

@@ -60,7 +60,7 @@ def test_configs3_100k_tiles_two_logical_shards(eng):
     np.testing.assert_array_equal(preds_g[:, 0], whole.f_mean)
     np.testing.assert_array_equal(preds_g[:, 1], whole.f_var)
     np.testing.assert_array_equal(preds_g[:, 2], whole.y_var)
-    assert (whole.status <= 1).mean() > 0.97 and not np.isin(whole.status, (2, 3)).any()
+    assert np.isin(whole.status, (0, 1, 6)).all() and (whole.status <= 1).mean() > 0.9
     # replicas differ (the per-replica scaling reached the kernels)
     assert len(np.unique(np.round(whole.nll[::NPROTO][:50], 6))) > 40
     # (b) spot tiles against the oracle at the returned parameters
