@@ -269,6 +269,9 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     a.ftol = b->ftol > 0 ? b->ftol : (b->ftol < 0 ? -1.0 : (f64 ? 2.220446049250313e-9 : 1e-6));
     a.gtol = b->gtol > 0 ? b->gtol : (b->gtol < 0 ? -1.0 : 1e-5);
     a.adam_lr = b->adam_lr > 0 ? b->adam_lr : 0.1;
+    // relative resolution of the objective: fp32 rounding ~ cond(K) eps N reaches 2e-4 |f| on the reference's 1-D tutorial
+    // tile (cond ~ 2e4, docs/notebooks/1d_local_expert_model_part_2.ipynb); fp64: rounding level only
+    a.noise_rel = f64 ? 1e-12 : 1e-3;
     a.obs_off = d_i64; a.pred_off = d_i64 + (T + 1);
     a.theta0 = d_f64; a.lo = d_f64 + (size_t)T * H; a.hi = d_f64 + 2 * (size_t)T * H;
     a.trainable = d_train;

@@ -10,6 +10,7 @@ namespace gpsat {
 struct KernelArgs {
     int T, kernel, optimiser, max_iter, max_ls, NBmax;
     double ftol, gtol, adam_lr;
+    double noise_rel;             // relative objective resolution of the arithmetic (line-search failure at the noise floor)
     const long long* obs_off;     // [T+1]
     const long long* pred_off;    // [T+1]
     const double* theta0;         // [T*H]

@@ -1123,7 +1123,7 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
 #endif
     OptCfg o;
     o.optimiser = A.optimiser; o.max_iter = A.max_iter; o.max_ls = A.max_ls; o.want_grad_out = A.grad != nullptr;
-    o.ftol = A.ftol; o.gtol = A.gtol; o.adam_lr = A.adam_lr;
+    o.ftol = A.ftol; o.gtol = A.gtol; o.adam_lr = A.adam_lr; o.noise_rel = A.noise_rel;
 
     for (;;) {
         __syncthreads();

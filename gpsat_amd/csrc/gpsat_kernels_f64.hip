@@ -809,7 +809,7 @@ __global__ void __launch_bounds__(NT, F64_MIN_WG) gp_tile_kernel_f64(const Kerne
     double* y_var = reinterpret_cast<double*>(A.y_var);
     OptCfg o;
     o.optimiser = A.optimiser; o.max_iter = A.max_iter; o.max_ls = A.max_ls; o.want_grad_out = A.grad != nullptr;
-    o.ftol = A.ftol; o.gtol = A.gtol; o.adam_lr = A.adam_lr;
+    o.ftol = A.ftol; o.gtol = A.gtol; o.adam_lr = A.adam_lr; o.noise_rel = A.noise_rel;
 
     for (;;) {
         __syncthreads();

@@ -148,6 +148,24 @@ static __device__ __noinline__ void ls_step(Shared* sh, int H, int max_ls) {
     }
     sh->ls_iter += 1;
     if (armijo && fabs(dphit) <= -c2 * sh->dphi0) { sh->ls_done = 1; return; }
+    if (sh->ls_phase == 1) {
+        // MINPACK-2 dcsrch's "XTOL TEST SATISFIED" (xtol = 0.1 in L-BFGS-B): this trial was placed inside a bracket
+        // whose relative width had already shrunk to 10 % -- the search ends here, and L-BFGS-B takes the step
+        // (lnsrlb treats the warning like convergence).  The sufficient-decrease point is taken: this trial if it is
+        // one, else the best one seen; with none at all the search has failed.
+        const double a0 = fmin(sh->t_lo, sh->t_hi), b0 = fmax(sh->t_lo, sh->t_hi);
+        if (b0 - a0 <= 0.1 * b0) {
+            if (armijo) { sh->ls_done = 1; return; }
+            if (sh->t_best > 0.0) {
+                sh->t = sh->t_best; sh->ft = sh->f_best;
+                for (int i = 0; i < H; ++i) { sh->ut[i] = sh->ub[i]; sh->gt[i] = sh->gb[i]; }
+                sh->ls_done = 3;          // accepted, but the factorisation in memory belongs to another point
+                return;
+            }
+            sh->ls_done = 2;
+            return;
+        }
+    }
     // max_ls evaluations without meeting the strong Wolfe conditions: failure, as L-BFGS-B's `iback >= maxls` (mainlb)
     if (sh->ls_iter >= max_ls) { sh->ls_done = 2; return; }
     if (sh->ls_phase == 0) {
@@ -201,7 +219,7 @@ enum { ST_CONVERGED = 0, ST_MAXITER = 1, ST_LS_FAILED = 6 };
 
 enum { PH_INIT = 0, PH_LS = 1, PH_ADAM = 2, PH_FINAL = 3, PH_EXIT = 4 };
 
-struct OptCfg { int optimiser, max_iter, max_ls, want_grad_out; double ftol, gtol, adam_lr; };
+struct OptCfg { int optimiser, max_iter, max_ls, want_grad_out; double ftol, gtol, adam_lr, noise_rel; };
 
 // the accepted point is sh->u; decide whether the factorisation in memory already belongs to it
 static __device__ __noinline__ void opt_finish(Shared* sh, int H, const OptCfg& o, bool factor_is_current) {
@@ -284,8 +302,9 @@ static __device__ __noinline__ void opt_advance(Shared* sh, int H, const OptCfg&
                 set_trial(sh, H, un);
                 return;
             }
-            if (sh->ls_done == 1) {
-                // accept the trial point (the last evaluated one)
+            if (sh->ls_done == 1 || sh->ls_done == 3) {
+                // accept the trial point (ls_done 1: the last evaluated one; 3: an earlier one, restored into ut / gt / ft)
+                const bool current = sh->ls_done == 1;
                 double sy = 0.0, yy = 0.0, gmax = 0.0;
                 double sv[HMAX], yvv[HMAX];
                 for (int i = 0; i < H; ++i) {
@@ -307,20 +326,20 @@ static __device__ __noinline__ void opt_advance(Shared* sh, int H, const OptCfg&
                 for (int i = 0; i < H; ++i) { sh->u[i] = sh->ut[i]; sh->g[i] = sh->gt[i]; gmax = fmax(gmax, fabs(sh->gt[i])); }
                 sh->iter += 1;
                 const double den = fmax(fmax(fabs(fold), fabs(fnew)), 1.0);
-                if ((fold - fnew) <= o.ftol * den || gmax <= o.gtol) { sh->status = 0; opt_finish(sh, H, o, true); return; }
-                if (sh->iter >= o.max_iter) { sh->status = 1; opt_finish(sh, H, o, true); return; }
+                if ((fold - fnew) <= o.ftol * den || gmax <= o.gtol) { sh->status = 0; opt_finish(sh, H, o, current); return; }
+                if (sh->iter >= o.max_iter) { sh->status = 1; opt_finish(sh, H, o, current); return; }
                 opt_start_iteration(sh, H, o);
                 return;
             }
             // Line search failed (no step satisfying the strong Wolfe conditions within max_ls evaluations).
-            //  * The last accepted step had already brought the decrease to within 100 x the ftol threshold: the objective
-            //    is being resolved at the noise floor of the arithmetic (fp32: rounding ~ cond(K) eps N), a further
-            //    decrease cannot be told from noise.  That is the finite-precision form of the ftol test: converged.
+            //  * The last accepted step's decrease was already at the resolution of the arithmetic (noise_rel * |f|: fp32
+            //    1e-3 -- the objective carries rounding ~ cond(K) eps N --, fp64 1e-12): a further decrease cannot be told
+            //    from noise.  That is the finite-precision form of the ftol test: converged.  (Not with ftol switched off.)
             //  * Otherwise as L-BFGS-B (mainlb, info != 0): with a non-empty history, discard it and restart once from
             //    steepest descent at the accepted point (the restart is not an iteration); with an empty history give up
             //    -- SciPy reports ABNORMAL_TERMINATION_IN_LNSRCH, success=False, hence a status of its own.  The best
             //    sufficient-decrease point seen by the failed search (if any) is kept rather than thrown away.
-            if (sh->iter > 0 && o.ftol > 0.0 && sh->last_dec <= 1e2 * o.ftol * fmax(fabs(sh->f), 1.0)) {
+            if (sh->iter > 0 && o.ftol >= 0.0 && sh->last_dec <= o.noise_rel * fmax(fabs(sh->f), 1.0)) {
                 sh->status = ST_CONVERGED;
                 opt_finish(sh, H, o, false);
                 return;

@@ -60,9 +60,9 @@ extern "C" {
 
 /* per-tile status */
 #define GPSAT_STATUS_CONVERGED 0   /* optimiser met ftol / gtol (scipy success=True); also: a line */
-                                   /*   search failed after a step whose decrease was already      */
-                                   /*   within 100 x the ftol threshold (objective resolved at the  */
-                                   /*   noise floor of the arithmetic)                              */
+                                   /*   search failed after a step whose decrease was already at   */
+                                   /*   the resolution of the arithmetic (1e-3 |f| in fp32, 1e-12   */
+                                   /*   |f| in fp64) -- not with ftol switched off                  */
 #define GPSAT_STATUS_MAXITER   1   /* iteration limit reached (scipy success=False)           */
 #define GPSAT_STATUS_NOT_PD    2   /* Cholesky failed at the initial / final parameters        */
 #define GPSAT_STATUS_NAN       3   /* NaN encountered                                          */

@@ -172,14 +172,19 @@ def test_status_follows_scipy(eng):
 
 
 def test_exact_iteration_count_mode(eng):
-    """ftol = gtol = off: every tile runs exactly max_iter iterations unless its line search fails (the bench's
-    'exact-iters' mode); n_eval >= n_iter + 1."""
+    """ftol = gtol = off (the bench's --exact-iters mode): a tile stops only at the iteration limit (status 1, exactly
+    max_iter iterations) or when its line search can no longer find a step (status 6, fewer iterations) -- in fp32 that
+    is where the objective's rounding noise hides any further decrease, so the objective reached is the converged one."""
     T, N, P, D = 16, 200, 8, 3
     b = syn.make_batch(T, N, P, D, 0, base_seed=4242)
     lo, hi = syn.default_bounds(T, D)
-    r = eng.fit_predict_batch(D=D, obs_off=b["obs_off"], X=b["X"], y=b["y"], pred_off=b["pred_off"], Xs=b["Xs"],
-                              theta0=np.ones((T, D + 2)), lo=lo, hi=hi, kernel="RBF", optimiser="lbfgs", max_iter=20,
-                              ftol=-1.0, gtol=-1.0)
+    kw = dict(D=D, obs_off=b["obs_off"], X=b["X"], y=b["y"], pred_off=b["pred_off"], Xs=b["Xs"], theta0=np.ones((T, D + 2)),
+              lo=lo, hi=hi, kernel="RBF", optimiser="lbfgs")
+    r = eng.fit_predict_batch(max_iter=20, ftol=-1.0, gtol=-1.0, **kw)
     assert set(np.unique(r.status)) <= {1, 6}
-    assert (r.n_iter[r.status == 1] == 20).all() and (r.n_eval >= r.n_iter + 1).all()
-    assert (r.status == 1).mean() >= 0.75
+    assert (r.n_iter[r.status == 1] == 20).all() and (r.n_iter[r.status == 6] < 20).all()
+    assert (r.n_eval >= r.n_iter + 1).all()
+    ref = eng.fit_predict_batch(max_iter=500, **kw)
+    assert (ref.status == 0).all()
+    done = r.status == 6
+    np.testing.assert_allclose(r.nll[done], ref.nll[done], rtol=0, atol=1e-4 * N)
