@@ -6,7 +6,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p /tmp/dis
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -I$ROOT/include -I$ROOT/gpsat_amd/csrc --cuda-device-only -S $ROOT/gpsat_amd/csrc/gpsat_kernels.hip -o /tmp/dis/k2.s -Rpass-analysis=kernel-resource-usage "$@" 2> /tmp/dis/res2.txt
 grep -A9 "${KSEL:-ILi3ELi0}" /tmp/dis/res2.txt | grep "VGPRs\|Scratch\|Spill" | sed 's/.*remark: *//'
-awk -v pat="^_ZN5gpsat2w[48]14gp_tile_kernel${KSEL:-ILi3ELi0}" '$0 ~ pat {f=1} f{print} /\.end_amdhsa_kernel/{if(f){exit}}' /tmp/dis/k2.s > /tmp/dis/k30b.s
+awk -v pat="^_ZN5gpsat2(w4|w8|v2)14gp_tile_kernel${KSEL:-ILi3ELi0}" '$0 ~ pat {f=1} f{print} /\.end_amdhsa_kernel/{if(f){exit}}' /tmp/dis/k2.s > /tmp/dis/k30b.s
 python3 - <<'PY'
 import re
 lines=open('/tmp/dis/k30b.s').read().split('\n')
