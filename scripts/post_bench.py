@@ -1,7 +1,10 @@
 """Timing of the post-processing kernels on the GPU box (no oracle): smoothing of T expert locations and gluing of R
 overlapping prediction rows; prints kernel ms from gpsat_last_timing and the NumPy host equivalent beside it."""
+import os
+import sys
 import time
 import ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gpsat_amd.engine import default_engine
 
