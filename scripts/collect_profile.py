@@ -34,14 +34,12 @@ if "stats" in dirs:
                             "Workgroup_Size", "Grid_Size", "Start_Timestamp", "End_Timestamp") if k in rows[0]]
         with open(os.path.join(out, "launches.csv"), "w", newline="") as fh:
             w = csv.writer(fh)
-            w.writerow(keep + ["duration_ms", "waves_per_simd_by_vgpr", "workgroups_per_cu_by_lds"])
+            # (the trace reports the architected half of the unified VGPR file and no dynamic LDS: occupancy is stated in
+            #  DESIGN.md from the compiler's resource report and the launch's dynamic LDS size)
+            w.writerow(keep + ["duration_ms"])
             for r in rows:
                 dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-                vg = int(r.get("VGPR_Count", 0) or 0) + int(r.get("Accum_VGPR_Count", 0) or 0)
-                alloc = max(8, -(-vg // 8) * 8)
-                lds = int(r.get("LDS_Block_Size", 0) or 0)
-                w.writerow([r[k][:70] if k == "Kernel_Name" else r[k] for k in keep] +
-                           [f"{dur:.3f}", min(8, 512 // alloc), (160 * 1024 // lds) if lds else ""])
+                w.writerow([r[k][:70] if k == "Kernel_Name" else r[k] for k in keep] + [f"{dur:.3f}"])
 res = {}
 for key in ("fetch", "write", "mfma", "sq1", "sq2"):
     if key in dirs:
