@@ -60,7 +60,7 @@ struct gpsat_handle {
     double last_kernel_ms = 0.0, last_total_ms = 0.0;
     // device buffers (grown lazily, owned by the handle)
     DevBuf meta_i64, meta_f64, meta_misc, out_f64, out_i32, bulk_in, bulk_out, ws, prof;
-    DevBuf sel_pts, sel_refs, sel_cnt, sel_idx;
+    DevBuf sel_pts, sel_refs, sel_cnt, sel_idx, sel_box;
     unsigned long long prof_host[64] = {0};
 };
 
@@ -126,7 +126,7 @@ int gpsat_destroy(gpsat_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->meta_i64.release(); h->meta_f64.release(); h->meta_misc.release(); h->out_f64.release();
     h->out_i32.release(); h->bulk_in.release(); h->bulk_out.release(); h->ws.release(); h->prof.release();
-    h->sel_pts.release(); h->sel_refs.release(); h->sel_cnt.release(); h->sel_idx.release();
+    h->sel_pts.release(); h->sel_refs.release(); h->sel_cnt.release(); h->sel_idx.release(); h->sel_box.release();
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -356,8 +356,9 @@ int gpsat_select_batch(gpsat_handle* h, const gpsat_select_spec* sp, int64_t M, 
     // row chunks: enough workgroups to fill the chip (T/32 workgroups per chunk), chunk a multiple of 64 rows
     const int wgs_per_chunk = std::max(1, (T + 31) / 32);
     int n_chunks = (int)std::min<long long>(std::max<long long>(1, (4096 + wgs_per_chunk - 1) / wgs_per_chunk), std::max<long long>(1, (M + 4095) / 4096));
-    long long chunk_rows = ((M + n_chunks - 1) / n_chunks + 63) / 64 * 64;
-    if (chunk_rows < 64) chunk_rows = 64;
+    const long long sub = gpsat::select_sub_rows();             // rows per bounding box: chunks are whole numbers of them
+    long long chunk_rows = ((M + n_chunks - 1) / n_chunks + sub - 1) / sub * sub;
+    if (chunk_rows < sub) chunk_rows = sub;
     n_chunks = (int)std::max<long long>(1, (M + chunk_rows - 1) / chunk_rows);
     const size_t ncell = (size_t)T * n_chunks;
     if ((rc = h->sel_cnt.reserve(2 * ncell * sizeof(long long)))) return rc;
@@ -370,6 +371,14 @@ int gpsat_select_batch(gpsat_handle* h, const gpsat_select_spec* sp, int64_t M, 
     a.counts = static_cast<long long*>(h->sel_cnt.p);
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+    a.box = nullptr;
+    if (M > 0) {
+        // per-column [min, max] of every `sub` rows: lets a wave skip sub-chunks none of its experts can select from
+        const size_t nsub = (size_t)((M + sub - 1) / sub);
+        if ((rc = h->sel_box.reserve(nsub * C * 2 * sizeof(double)))) return rc;
+        HIP_TRY(gpsat::launch_select_boxes(M, C, a.pts, static_cast<double*>(h->sel_box.p), h->stream));
+        a.box = static_cast<const double*>(h->sel_box.p);
+    }
     HIP_TRY(gpsat::launch_select(a, false, h->stream));
     std::vector<long long> cnt(ncell);
     HIP_TRY(hipMemcpyAsync(cnt.data(), a.counts, ncell * sizeof(long long), hipMemcpyDeviceToHost, h->stream));

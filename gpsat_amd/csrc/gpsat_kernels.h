@@ -75,9 +75,12 @@ struct SelectArgs {
     long long* counts;                // [T][n_chunks]   (count pass)
     const long long* off;             // [T][n_chunks] start offsets (fill pass)
     int* idx;                         // [off[T]] (fill pass)
+    const double* box;                // [ceil(M / sub)][C][2] per-column [min, max] of every sub-chunk of rows, or nullptr
 };
 
 hipError_t launch_select(const SelectArgs& a, bool fill, hipStream_t stream);
+hipError_t launch_select_boxes(long long M, int C, const double* pts, double* box, hipStream_t stream);
+int select_sub_rows();      // rows per box; chunk_rows must be a multiple of it
 
 #define GPSAT_GLUE_MAXVARS 4
 // post-processing (gpsat_post.hip); device pointers

@@ -10,6 +10,15 @@
 //   products and sums are NOT contracted into FMAs (__dmul_rn / __dadd_rn), as in the reference's host code.
 // Output per expert: the selected row indices in SOURCE ROW ORDER (dataloader.py:2447), CSR-packed.
 //
+// Sub-chunk skipping.  A first kernel reduces every SEL_SUB consecutive rows to their per-column [min, max] box.  Before
+// a wave streams a sub-chunk it tests, for its EB experts, whether ANY row of the box can satisfy ALL criteria; if none
+// can for any of them, the sub-chunk is skipped (only its box, 1/64 of its bytes, was read).  The test is exact, not
+// heuristic: IEEE subtraction, multiplication and addition are monotone, so the squared distance of the box's nearest
+// point, accumulated in the reference's order, is a lower bound of every row's; 1-D comparisons are tested against the
+// box ends.  Source tables that are ordered in time or along the satellite track (GPSat's are: daily files appended)
+// skip almost everything outside an expert's window; on randomly ordered rows nothing is skipped and the box read
+// costs 1.6 % more traffic.  Membership and output order are unchanged either way.
+//
 // This is HBM/L2-bound streaming + integer compaction: no MFMA.  One wave owns EB experts and streams the point
 // columns (SoA, coalesced 512-B wave reads, L2/MALL-resident across experts); matches are compacted with
 // ballot / popcount / mbcnt, so no LDS and no barriers.  The rows are cut into chunks (grid.y) so that the launch
@@ -22,6 +31,39 @@ namespace gpsat {
 
 constexpr int SEL_EB = 8;        // experts per wave
 constexpr int SEL_NT = 256;      // threads per workgroup (4 independent waves)
+constexpr int SEL_SUB = 1024;    // rows per bounding box (a multiple of 64; chunk_rows is a multiple of it)
+
+// per-column [min, max] of every SEL_SUB consecutive rows: box[(sub * C + c) * 2 + {0, 1}]; one wave per sub-chunk
+__global__ void __launch_bounds__(256) select_box_kernel(long long M, int C, const double* __restrict__ pts, double* __restrict__ box) {
+    const int lane = threadIdx.x & 63;
+    const long long sub = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long r0 = sub * SEL_SUB;
+    if (r0 >= M) return;
+    const long long r1 = min(M, r0 + SEL_SUB);
+    for (int c = 0; c < C; ++c) {
+        double mn = __builtin_inf(), mx = -__builtin_inf();
+        for (long long i = r0 + lane; i < r1; i += 64) {
+            const double x = pts[(size_t)c * M + i];
+            mn = fmin(mn, x);            // fmin / fmax ignore a NaN operand; an all-NaN column leaves (+inf, -inf): never skipped
+            mx = fmax(mx, x);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { mn = fmin(mn, __shfl_xor(mn, o)); mx = fmax(mx, __shfl_xor(mx, o)); }
+        if (!(mn <= mx)) { mn = -__builtin_inf(); mx = __builtin_inf(); }       // no usable bound: the box excludes nothing
+        if (lane == 0) { box[((size_t)sub * C + c) * 2] = mn; box[((size_t)sub * C + c) * 2 + 1] = mx; }
+    }
+}
+
+// can a row with x in [mn, mx] satisfy  x <comp> y ?
+__device__ __forceinline__ bool cmp1d_possible(int comp, double mn, double mx, double y) {
+    switch (comp) {
+        case 0: return mx >= y;
+        case 1: return mx > y;
+        case 2: return mn <= y && y <= mx;
+        case 3: return mn < y;
+        default: return mn <= y;
+    }
+}
 
 __device__ __forceinline__ bool cmp1d(int comp, double x, double y) {
     switch (comp) {
@@ -68,7 +110,39 @@ __global__ void __launch_bounds__(SEL_NT) select_kernel(const SelectArgs a) {
     long long cnt[SEL_EB];
 #pragma unroll
     for (int e = 0; e < SEL_EB; ++e) cnt[e] = FILL ? a.off[(size_t)(e0 + min(e, ne - 1)) * a.n_chunks + ch] : 0;
-    for (long long base = r_beg; base < r_end; base += 64) {
+    for (long long sbeg = r_beg; sbeg < r_end; sbeg += SEL_SUB) {
+      // ---- can any of this wave's experts select a row of this sub-chunk?  (wave-uniform arithmetic on its box)
+      if (a.box) {
+        const double* bx = a.box + (size_t)(sbeg / SEL_SUB) * a.C * 2;
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < SEL_EB; ++e) {
+            bool poss = e < ne;
+#pragma unroll
+            for (int k = 0; k < GPSAT_SEL_MAXCRIT; ++k) {
+                if (k < a.n_crit) {
+                    if (a.kind[k] == 0) {
+                        const int cl = a.cols[k][0];
+                        poss = poss && cmp1d_possible(a.comp[k], bx[cl * 2], bx[cl * 2 + 1], rhs[e][k]);
+                    } else {
+                        double sl = 0.0;     // squared distance of the box's nearest point, the reference's operation order
+                        for (int m = 0; m < a.ncols[k]; ++m) {
+                            const int cl = a.cols[k][m];
+                            const double c0 = rc[e][k][m];
+                            const double lo = __dsub_rn(bx[cl * 2], c0), hi = __dsub_rn(bx[cl * 2 + 1], c0);   // monotone in x
+                            const double d = (lo > 0.0) ? lo : ((hi < 0.0) ? hi : 0.0);
+                            sl = __dadd_rn(sl, __dmul_rn(d, d));
+                        }
+                        poss = poss && (a.comp[k] == 3 ? (sl < rhs[e][k]) : (sl <= rhs[e][k]));
+                    }
+                }
+            }
+            any = any || poss;
+        }
+        if (!any) continue;
+      }
+      const long long send = min(r_end, sbeg + SEL_SUB);
+      for (long long base = sbeg; base < send; base += 64) {
         const long long i = base + lane;
         const bool inb = i < r_end;
         // this lane's point: the columns any criterion needs (at most MAXCRIT * 3 loads, L1/L2 hits)
@@ -108,6 +182,7 @@ __global__ void __launch_bounds__(SEL_NT) select_kernel(const SelectArgs a) {
             }
             cnt[e] += __popcll(bal);
         }
+      }
     }
     if (!FILL && lane == 0) {
 #pragma unroll
@@ -115,6 +190,14 @@ __global__ void __launch_bounds__(SEL_NT) select_kernel(const SelectArgs a) {
             if (e < ne) a.counts[(size_t)(e0 + e) * a.n_chunks + ch] = cnt[e];
     }
 }
+
+hipError_t launch_select_boxes(long long M, int C, const double* pts, double* box, hipStream_t stream) {
+    const long long nsub = (M + SEL_SUB - 1) / SEL_SUB;
+    if (nsub > 0) hipLaunchKernelGGL(select_box_kernel, dim3((unsigned)((nsub + 3) / 4)), dim3(256), 0, stream, M, C, pts, box);
+    return hipGetLastError();
+}
+
+int select_sub_rows() { return SEL_SUB; }
 
 hipError_t launch_select(const SelectArgs& a, bool fill, hipStream_t stream) {
     const int waves = (a.T + SEL_EB - 1) / SEL_EB;

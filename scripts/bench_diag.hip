@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <vector>
 using namespace gpsat;
+using namespace gpsat::w4;
 
 __global__ void __launch_bounds__(64) k_diag(const float* in, float* out, unsigned long long* cyc, int reps) {
     const int lane = threadIdx.x;

@@ -17,6 +17,13 @@ import ctypes as C
 km, tm = C.c_double(), C.c_double(); eng._lib.gpsat_last_timing(eng._h, C.byref(km), C.byref(tm))
 print(f"device: count+fill kernels {km.value:.1f} ms, with copies {tm.value:.1f} ms")
 print(f"device: T={T} M={M}: {dt*1e3:.1f} ms wall ({T/dt:.0f} tiles/s), mean N/tile {off[-1]/T:.0f}, {T*M/dt/1e9:.1f} G predicate-rows/s")
+# the same table ordered by day (how GPSat's tables come): sub-chunks outside the +-4 day window are skipped by their boxes
+dfs = df.sort_values("t", kind="stable").reset_index(drop=True)
+dss = DeviceSelector(dfs, ls, eng)
+dss.select(xl.iloc[:8])
+t0 = time.perf_counter(); off2, idx2 = dss.select(xl); dt2 = time.perf_counter() - t0
+eng._lib.gpsat_last_timing(eng._h, C.byref(km), C.byref(tm))
+print(f"device, rows ordered by day: kernels {km.value:.1f} ms, {dt2*1e3:.1f} ms wall ({T/dt2:.0f} tiles/s), same selection size: {off2[-1] == off[-1]}")
 hs = LocalSelector(df, ls)
 t0 = time.perf_counter()
 for t in range(64):
