@@ -24,6 +24,16 @@ dss.select(xl.iloc[:8])
 t0 = time.perf_counter(); off2, idx2 = dss.select(xl); dt2 = time.perf_counter() - t0
 eng._lib.gpsat_last_timing(eng._h, C.byref(km), C.byref(tm))
 print(f"device, rows ordered by day: kernels {km.value:.1f} ms, {dt2*1e3:.1f} ms wall ({T/dt2:.0f} tiles/s), same selection size: {off2[-1] == off[-1]}")
+# GPSat's usual sweep: all expert locations of one run share the day (a grid at t = const)
+xl1 = xl.assign(t=15.0)
+dss.select(xl1.iloc[:8])
+t0 = time.perf_counter(); off3, idx3 = dss.select(xl1); dt3 = time.perf_counter() - t0
+eng._lib.gpsat_last_timing(eng._h, C.byref(km), C.byref(tm))
+print(f"device, rows ordered by day, experts of one day: kernels {km.value:.1f} ms, {dt3*1e3:.1f} ms wall ({T/dt3:.0f} tiles/s), mean N/tile {off3[-1]/T:.0f}")
+ds.select(xl1.iloc[:8])
+t0 = time.perf_counter(); off4, idx4 = ds.select(xl1); dt4 = time.perf_counter() - t0
+eng._lib.gpsat_last_timing(eng._h, C.byref(km), C.byref(tm))
+print(f"device, rows in random order, experts of one day: kernels {km.value:.1f} ms, {dt4*1e3:.1f} ms wall")
 hs = LocalSelector(df, ls)
 t0 = time.perf_counter()
 for t in range(64):
