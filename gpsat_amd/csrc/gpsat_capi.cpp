@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -220,6 +221,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
                             : (w8 ? gpsat::shared_bytes_w8(D, NBmax) : gpsat::shared_bytes(D, NBmax));
     if (smem > 160 * 1024) return fail(GPSAT_EINVAL, "tile too large for LDS");
     if (w8 || (f64 && !d4)) grid = std::min(grid, h->num_cu);
+    if (const char* e = std::getenv("GPSAT_DEBUG_GRID")) grid = std::max(1, std::min(grid, std::atoi(e)));   // developer: fewer resident workgroups
     if ((rc = h->ws.reserve((size_t)grid * wsf * esz))) return rc;
 
     const char *dX = nullptr, *dy = nullptr, *dXs = nullptr;
