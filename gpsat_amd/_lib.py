@@ -58,11 +58,32 @@ class LibraryMissing(ImportError):
     pass
 
 
+def _one_hip_runtime():
+    """A process must use ONE HIP runtime.  PyTorch wheels bundle their own libamdhip64 (same SONAME as the system ROCm's);
+    whichever is loaded first serves both.  If this library came first with the system runtime, a later `import torch` +
+    CUDA initialisation finds "No HIP GPUs"; the other way round works.  So when PyTorch is installed, its runtime is
+    loaded first -- without importing torch."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     if not os.path.exists(LIB_PATH):
         raise LibraryMissing(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C gpsat_amd/csrc` (there is no CPU fallback)")
+    _one_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name in EXPORTS:
         if not hasattr(lib, name):

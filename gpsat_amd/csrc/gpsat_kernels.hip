@@ -147,11 +147,21 @@ __device__ __forceinline__ int wave_pull(int* counter, int lane) {
 // ---------------------------------------------------------------------------------------------
 // covariance functions.  r2 is the squared scaled distance.
 //   kf = k(r), gg = g(r) with dk/dl_d = g(r) (x_d-x'_d)^2 / l_d^3   (both without sigma_f^2)
+// f32 MFMA and every other vector instruction take turns on the SIMD (scripts/bench_coissue.hip: nothing issues beside
+// a v_mfma_f32_32x32x2_f32, ~5 cycles per VALU instruction on top of 64 per MFMA), so each instruction per matrix
+// element saved here is paid back in full.  RBF: the coordinates in LDS carry the factor KSC = sqrt(log2(e) / 2) on top
+// of 1 / l, so that exp(-r^2 / 2) is ONE v_exp_f32 of the accumulated squared distance.
 // ---------------------------------------------------------------------------------------------
 template <int KERN>
+struct KScale {                            // factor folded into the scaled coordinates, and its square
+    static constexpr float c = (KERN == 0) ? 0.8493218002880191f : 1.0f;
+    static constexpr float c2 = (KERN == 0) ? 0.7213475204444817f : 1.0f;
+};
+
+template <int KERN>
 __device__ __forceinline__ void kfun(float r2, float& kf, float& gg) {
-    if (KERN == 0) {                       // RBF: exp(-r2/2)
-        kf = __expf(-0.5f * r2);
+    if (KERN == 0) {                       // RBF: exp(-r^2/2) = 2^(-r2) on the prescaled distance
+        kf = __builtin_amdgcn_exp2f(-r2);
         gg = kf;
     } else {
         float r = sqrtf(fmaxf(r2, 1e-36f));
@@ -204,6 +214,27 @@ __device__ __forceinline__ f32x16 kblock_t(const Ctx<D, KERN>& c, int bi, int bj
 #pragma unroll
     for (int d = 0; d < D; ++d) xq[d] = lds_f[c.L.xsc + d * c.Npad + q];
     f32x16 out;
+    if (bi != bj && 32 * bi + 32 <= c.N && 32 * bj + 32 <= c.N) {
+        // interior off-diagonal block (most of them): no padding, no diagonal -- nothing to mask
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int p0 = 32 * bi + 8 * qq + 4 * c.h;
+            float r2[4];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                f32x4 xp = *reinterpret_cast<const f32x4*>(lds_f + c.L.xsc + d * c.Npad + p0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float df = xp[e] - xq[d]; r2[e] = (d == 0) ? df * df : fmaf(df, df, r2[e]); }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float kf, gg;
+                kfun<KERN>(r2[e], kf, gg);
+                out[4 * qq + e] = c.sf2 * kf;
+            }
+        }
+        return out;
+    }
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
         const int p0 = 32 * bi + 8 * qq + 4 * c.h;
@@ -284,6 +315,37 @@ __device__ __forceinline__ void contract_t(const Ctx<D, KERN>& c, const f32x16& 
 #pragma unroll
         for (int d = 0; d < D; ++d) xp[qq][d] = *reinterpret_cast<const f32x4*>(lds_f + c.L.xsc + d * c.Npad + p0);
         ap[qq] = *reinterpret_cast<const f32x4*>(lds_f + c.L.alpha + p0);
+    }
+    if (ba != bb && 32 * ba + 32 <= c.N && 32 * bb + 32 <= c.N) {
+        // interior off-diagonal block: no masks, no diagonal term; the block weight is applied once to the block's sums
+        float bl[D], bsf = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) bl[d] = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float d2[D];
+                float r2 = 0.f;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const float df = xp[qq][d][e] - xq[d];
+                    d2[d] = df * df;
+                    r2 = (d == 0) ? d2[d] : r2 + d2[d];
+                }
+                float kf, gg;
+                kfun<KERN>(r2, kf, gg);
+                const float Q = fmaf(-ap[qq][e], aq, kinv[4 * qq + e]);
+                bsf = fmaf(Q, kf, bsf);
+                const float wg = Q * gg;
+#pragma unroll
+                for (int d = 0; d < D; ++d) bl[d] = fmaf(wg, d2[d], bl[d]);
+            }
+        }
+        accsf = fmaf(wgt, bsf, accsf);
+#pragma unroll
+        for (int d = 0; d < D; ++d) accl[d] = fmaf(wgt, bl[d], accl[d]);
+        return;
     }
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
@@ -911,7 +973,7 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
             double s = 0.0;
             for (int ww = 0; ww < NW; ++ww) s += sh->red[ww][i];
             // scaled diff^2 already carries 1/l^2 (dk/dl = g diff^2 / l^3); kf, g are without sf2
-            if (i < D) sh->gth[i] = 0.5 * (double)c.sf2 * s / sh->theta[i];
+            if (i < D) sh->gth[i] = 0.5 * (double)c.sf2 * (s / (double)KScale<KN>::c2) / sh->theta[i];
             else sh->gth[i] = 0.5 * s;
         }
     }
@@ -944,7 +1006,7 @@ __device__ __forceinline__ void evaluate(Ctx<D, KN>& c, bool want_grad) {
     PROF_BEGIN();
     float invl[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) invl[d] = (float)(1.0 / sh->theta[d]);
+    for (int d = 0; d < D; ++d) invl[d] = (float)((double)KScale<KN>::c / sh->theta[d]);
     c.sf2 = (float)sh->theta[D];
     c.sn2 = (float)sh->theta[D + 1];
     for (int idx = c.tid; idx < c.Npad; idx += NT) {
@@ -1165,7 +1227,7 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
                     float r2 = 0.f;
 #pragma unroll
                     for (int d = 0; d < D; ++d) {
-                        const float il = (float)(1.0 / A.theta0[(size_t)t * H + d]);
+                        const float il = (float)((double)KScale<KN>::c / A.theta0[(size_t)t * H + d]);
                         const float df = (A.Xs[(size_t)(p0 + i) * D + d] - A.Xs[(size_t)(p0 + j) * D + d]) * il;
                         r2 = fmaf(df, df, r2);
                     }
@@ -1231,7 +1293,7 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
             if (!sh->fail) {
                 float invl[D];
 #pragma unroll
-                for (int d = 0; d < D; ++d) invl[d] = (float)(1.0 / sh->theta[d]);
+                for (int d = 0; d < D; ++d) invl[d] = (float)((double)KScale<KN>::c / sh->theta[d]);
                 predict_tile<D, KN>(c, A.Xs + (size_t)p0 * D, A.f_mean + p0, A.f_var + p0, A.y_var + p0, invl,
                                     A.f_cov ? A.f_cov + A.cov_off[t] : nullptr);
             } else {
