@@ -1182,6 +1182,7 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
     c.prof = sh->prof;
 #ifdef GPSAT_PROFILE
     if (c.tid < NW * 16) sh->prof[c.tid] = 0ull;
+    const unsigned long long prof_k0 = __builtin_amdgcn_s_memtime(), prof_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     OptCfg o;
     o.optimiser = A.optimiser; o.max_iter = A.max_iter; o.max_ls = A.max_ls; o.want_grad_out = A.grad != nullptr;
@@ -1306,6 +1307,11 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
         }
     }
 #ifdef GPSAT_PROFILE
+    __syncthreads();
+    if (blockIdx.x == 0 && c.tid == 0) {       // whole-kernel span of workgroup 0 in both clocks: s_memtime ticks per 100 MHz tick
+        sh->prof[14] = __builtin_amdgcn_s_memtime() - prof_k0;
+        sh->prof[15] = __builtin_amdgcn_s_memrealtime() - prof_r0;
+    }
     __syncthreads();
     if (A.prof && c.tid < NW * 16) atomicAdd(&A.prof[c.tid], sh->prof[c.tid]);
 #endif

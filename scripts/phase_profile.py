@@ -30,6 +30,8 @@ for name, kw in [("potrf only", dict(optimiser="none")), ("potrf+trtri+grad", di
     lib.gpsat_debug_profile(eng._h, buf)
     prof = np.array(buf[:], dtype=np.float64).reshape(4, 16)
     print(f"== {name}: kernel {r.kernel_ms:.2f} ms; cycles per evaluation per wave (s_memtime ticks, 100MHz?)")
+    print(f"   workgroup 0: {prof[0, 14]:.0f} s_memtime ticks in {prof[0, 15]:.0f} ticks of the 100 MHz clock -> s_memtime runs at "
+          f"{prof[0, 14] / max(prof[0, 15], 1) * 100:.0f} MHz; events say {r.kernel_ms:.3f} ms")
     per_eval = prof / T
     for i, nme in enumerate(names):
         print(f"   {nme:22s} " + " ".join(f"w{w}:{per_eval[w, i]:10.0f}" for w in range(4)))
