@@ -62,7 +62,7 @@ struct gpsat_handle {
     // device buffers (grown lazily, owned by the handle)
     DevBuf meta_i64, meta_f64, meta_misc, out_f64, out_i32, bulk_in, bulk_out, ws, prof;
     DevBuf sel_pts, sel_refs, sel_cnt, sel_idx, sel_box;
-    unsigned long long prof_host[64] = {0};
+    unsigned long long prof_host[64 + 8 * 1024] = {0};     // counters + event trace (diagnostic build)
 };
 
 extern "C" {
@@ -291,8 +291,8 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     a.f_cov = want_cov ? reinterpret_cast<float*>(dcov) : nullptr;
     a.PCmax = PCcov;
 #ifdef GPSAT_PROFILE
-    if ((rc = h->prof.reserve(64 * sizeof(unsigned long long)))) return rc;
-    HIP_TRY(hipMemsetAsync(h->prof.p, 0, 64 * sizeof(unsigned long long), h->stream));
+    if ((rc = h->prof.reserve(sizeof(h->prof_host)))) return rc;
+    HIP_TRY(hipMemsetAsync(h->prof.p, 0, sizeof(h->prof_host), h->stream));
     a.prof = static_cast<unsigned long long*>(h->prof.p);
 #endif
 
@@ -315,7 +315,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     if (b->memory == GPSAT_MEM_HOST && want_cov && sumC > 0)
         HIP_TRY(hipMemcpyAsync(b->f_cov, dcov, (size_t)sumC * esz, hipMemcpyDeviceToHost, h->stream));
 #ifdef GPSAT_PROFILE
-    HIP_TRY(hipMemcpyAsync(h->prof_host, h->prof.p, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->prof_host, h->prof.p, sizeof(h->prof_host), hipMemcpyDeviceToHost, h->stream));
 #endif
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -475,7 +475,13 @@ int gpsat_glue_batch(gpsat_handle* h, int64_t R, int32_t G, int32_t ndim, int32_
 // diagnostic build only: per-wave, per-segment cycle counters of the last call ([4 waves][16 slots])
 int gpsat_debug_profile(gpsat_handle* h, unsigned long long* out64) {
     if (!h || !out64) return GPSAT_EINVAL;
-    std::memcpy(out64, h->prof_host, sizeof(h->prof_host));
+    std::memcpy(out64, h->prof_host, 64 * sizeof(unsigned long long));
+    return GPSAT_OK;
+}
+// event trace of the first evaluation of workgroup 0: [8 waves][1024] entries (cycle << 16 | arg << 8 | code), 0 = unused
+int gpsat_debug_trace(gpsat_handle* h, unsigned long long* out8192) {
+    if (!h || !out8192) return GPSAT_EINVAL;
+    std::memcpy(out8192, h->prof_host + 64, 8 * 1024 * sizeof(unsigned long long));
     return GPSAT_OK;
 }
 #endif

@@ -39,9 +39,19 @@
         if ((c_).lane == 0) (c_).prof[(c_).w * 16 + (slot_)] += t1_ - prof_t_;               \
         prof_t_ = t1_;                                                                       \
     } while (0)
+// event trace of ONE evaluation of workgroup 0 (scripts/phase_timeline.py): (cycle << 16) | (arg << 8) | code per wave
+#define TRACE(c_, code_, arg_)                                                                        \
+    do {                                                                                              \
+        if ((c_).trace && (c_).lane == 0 && shared_state()->tron) {                                   \
+            const int i_ = shared_state()->tcnt[(c_).w]++;                                            \
+            if (i_ < 1024) (c_).trace[(c_).w * 1024 + i_] = (__builtin_amdgcn_s_memtime() << 16) |    \
+                                                           ((unsigned long long)((arg_) & 255) << 8) | (code_); \
+        }                                                                                             \
+    } while (0)
 #else
 #define PROF_BEGIN() do {} while (0)
 #define PROF_END(c_, slot_) do {} while (0)
+#define TRACE(c_, code_, arg_) do {} while (0)
 #endif
 
 // Two builds of this file are linked: the default (4 waves per workgroup, two workgroups per CU when the tile's LDS
@@ -86,6 +96,9 @@ __device__ __forceinline__ f32x16 pack16(const f32x4& a, const f32x4& b, const f
 
 // global block `blk` of the workgroup's workspace
 __device__ __forceinline__ f32x16 ldg(const float* __restrict__ ws, int blk, int lane) {
+#ifdef GPSAT_EXP_CACHED          // experiment: every operand block load hits one of 8 blocks (results are garbage)
+    blk &= 7;
+#endif
     const f32x4* q = reinterpret_cast<const f32x4*>(ws + (size_t)blk * BLK) + lane;
     return pack16(q[0], q[64], q[128], q[192]);
 }
@@ -112,8 +125,20 @@ __device__ __forceinline__ void stl(int off, int lane, const f32x16& v) {
 
 // acc += S_A^T * S_B   (16 x v_mfma_f32_32x32x2_f32)
 __device__ __forceinline__ void mma_blk(f32x16& acc, const f32x16& a, const f32x16& b) {
+#if GPSAT_EXP_ABL == 3           // ablation: half of the MFMAs
+    for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s] + a[s + 8], b[s], acc, 0, 0, 0);
+#elif GPSAT_EXP_ABL == 4         // ablation: one MFMA per block product (the skeleton without the matrix work)
+    float sa = 0.f, sb = 0.f;
+    for (int s = 0; s < 16; ++s) { sa += a[s]; sb += b[s]; }
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sa, sb, acc, 0, 0, 0);
+    return;
+#elif GPSAT_EXP_ABL == 5         // ablation: 24 MFMAs per block product
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s + 8], acc, 0, 0, 0);
+#else
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+#endif
 }
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -182,6 +207,10 @@ __device__ __forceinline__ void kfun(float r2, float& kf, float& gg) {
     }
 }
 
+#ifndef GPSAT_EXP_ABL
+#define GPSAT_EXP_ABL 0          // developer ablations (scripts/eval_bench.py); 0 in every shipped build
+#endif
+#define GPSAT_PT_MAXNB 100      // block columns of the largest tile (gpsat_max_tile_obs: 3168 = 99 * 32)
 #include "gpsat_opt.h"
 
 constexpr int SHARED_FLOATS = (int)((sizeof(Shared) + 15) / 16) * 4;
@@ -200,6 +229,7 @@ struct Ctx {
     int tid, lane, w, h, g;
     float sf2, sn2;
     unsigned long long* prof;    // LDS, [NW][16] (diagnostic build)
+    unsigned long long* trace;   // global, [NW][1024] (diagnostic build, workgroup 0 only)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -209,6 +239,9 @@ struct Ctx {
 // ---------------------------------------------------------------------------------------------
 template <int D, int KERN>
 __device__ __forceinline__ f32x16 kblock_t(const Ctx<D, KERN>& c, int bi, int bj) {
+#if GPSAT_EXP_ABL == 1           // ablation: no K-block generation
+    { f32x16 o; for (int r = 0; r < 16; ++r) o[r] = (bi == bj && rho(r, c.h) == c.g) ? 2.f : 0.001f; return o; }
+#endif
     const int q = 32 * bj + c.g;
     float xq[D];
 #pragma unroll
@@ -301,6 +334,9 @@ __device__ __forceinline__ f32x16 ksblock(const Ctx<D, KN>& c, int bj, const flo
 template <int D, int KERN>
 __device__ __forceinline__ void contract_t(const Ctx<D, KERN>& c, const f32x16& kinv, int ba, int bb, float wgt,
                                            float (&accl)[D], float& accsf, float& accsn) {
+#if GPSAT_EXP_ABL == 1 || GPSAT_EXP_ABL == 6          // ablation: no contraction
+    accsf += kinv[0]; return;
+#endif
     const int q = 32 * bb + c.g;
     float xq[D];
 #pragma unroll
@@ -406,6 +442,9 @@ __device__ __forceinline__ float lane_xor32(float x, int h) {
 __device__ __forceinline__ void diag_factor(const f32x16& W, int Ad, int piv, int lane, f32x16& S1, f32x16& S2,
                                             double& logsum, int& bad) {
     const int h = lane >> 5, g = lane & 31;
+#if GPSAT_EXP_ABL == 2           // ablation: no factorisation
+    S1 = W; S2 = W; logsum = 0.0; bad = 0; return;
+#endif
     f32x16 TA = W;
     f32x16 TE;
 #pragma unroll
@@ -425,6 +464,9 @@ __device__ __forceinline__ void diag_factor(const f32x16& W, int Ad, int piv, in
         float p11 = readlane_f(TA[r1], 32 * hp + k1);
         float det = p00 * p11 - p10 * p10;
         if (!(p00 > 0.f) || !(det > 0.f)) { isbad = 1; p00 = 1.f; p10 = 0.f; p11 = 1.f; det = 1.f; }
+#if defined(GPSAT_EXP_CACHED) || GPSAT_EXP_ABL
+        isbad = 0;
+#endif
         float rd = __builtin_amdgcn_rcpf(det);
         rd = rd * (2.f - det * rd);
         const bool mine = lane == s;
@@ -524,6 +566,32 @@ __device__ __forceinline__ void pt_group_kloop(const Ctx<D, KN>& c, const Panel<
     const int kmin = min(ks0, ks1);
 #pragma unroll
     for (int n = 0; n < 4; ++n) W[n] = zero16();
+#ifdef GPSAT_EXP_INPLACE        // experiment E13': slower by 1.2 % (the refill has 2048 instead of 4096 MFMA cycles to arrive)
+    if (kmin < j0) {
+        // Operand registers are refilled IN PLACE as soon as their last product of the step has issued (each then has two
+        // block products = 2048 MFMA cycles to arrive); only B0, used by the last and the first product, keeps a spare set.
+        // No register copies besides those 16 (a v_mov costs the f32 MFMA pipe its issue slot, see kfun).
+        f32x16 A0 = ldg(c.ws, kmin * NB + j0, lane);
+        f32x16 A1 = ldg(c.ws, p.has1 ? kmin * NB + p.j1 : c.zb, lane);
+        f32x16 B0 = ldg(c.ws, (kmin >= ks0) ? kmin * NB + c0 : c.zb, lane);
+        f32x16 B1 = ldg(c.ws, (kmin >= ks1) ? kmin * NB + c1 : c.zb, lane);
+        for (int k = kmin; k < j0; ++k) {
+            const int kn = min(k + 1, j0 - 1);          // the last step reloads its own blocks (harmless)
+            const f32x16 nB0 = ldg(c.ws, (kn >= ks0) ? kn * NB + c0 : c.zb, lane);
+            mma_blk(W[0], A0, B0);
+            mma_blk(W[1], A0, B1);
+            __builtin_amdgcn_sched_barrier(0);
+            A0 = ldg(c.ws, kn * NB + j0, lane);
+            mma_blk(W[3], A1, B1);
+            __builtin_amdgcn_sched_barrier(0);
+            B1 = ldg(c.ws, (kn >= ks1) ? kn * NB + c1 : c.zb, lane);
+            mma_blk(W[2], A1, B0);
+            __builtin_amdgcn_sched_barrier(0);
+            A1 = ldg(c.ws, p.has1 ? kn * NB + p.j1 : c.zb, lane);
+            B0 = nB0;
+        }
+    }
+#else
     if (kmin < j0) {
         f32x16 A0 = ldg(c.ws, kmin * NB + j0, lane);
         f32x16 A1 = ldg(c.ws, p.has1 ? kmin * NB + p.j1 : c.zb, lane);
@@ -545,6 +613,7 @@ __device__ __forceinline__ void pt_group_kloop(const Ctx<D, KN>& c, const Panel<
             A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
         }
     }
+#endif
     // U-type: W = K - acc ; M-type: W = -acc
     if (v0 && u0) {
         W[0] = kblock<D, KN>(c, j0, c0) - W[0];
@@ -599,6 +668,21 @@ __device__ __forceinline__ void pt_group_row(const Ctx<D, KN>& c, const Panel<D>
     }
 }
 
+// spin on a flag of the sweep (see phase_pt); false = the evaluation has failed, unwind
+__device__ __forceinline__ bool pt_wait(Shared* sh, const int* flag, int v) {
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) {
+        if (__hip_atomic_load(&sh->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 22)) {           // never reached by design (seconds); a lost flag must not hang the GPU
+            __hip_atomic_store(&sh->fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return false;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return true;
+}
+
 // D00 += U_k,j0^T U_k,j0, D01 += U_k,j0^T U_k,j1, D11 += U_k,j1^T U_k,j1 and the forward-solve partials for k in [kb, ke)
 template <int D, int KN>
 __device__ __forceinline__ void chain_kloop(const Ctx<D, KN>& c, const Panel<D>& p, int kb, int ke, f32x16& D00, f32x16& D01,
@@ -632,8 +716,8 @@ __device__ __forceinline__ void chain_kloop(const Ctx<D, KN>& c, const Panel<D>&
 // kwait: rows >= kwait of the panel columns are produced concurrently by another wave in this slot;
 // the chain polls sh->g0done (>= slot) before touching them.
 template <int D, int KN>
-__device__ __forceinline__ void pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const Panel<D>& q, const bool want_m, int par,
-                                         int kwait, int slot, bool held) {
+__device__ __forceinline__ bool pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const Panel<D>& q, const bool want_m, int par,
+                                         int kwait, int slot, bool held, int lt_users) {
     Shared* sh = shared_state();
     const int NB = c.NB, lane = c.lane;
     const int j0 = p.j0, j1 = p.j1;
@@ -641,19 +725,31 @@ __device__ __forceinline__ void pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const
     f32x16 D00 = zero16(), D01 = zero16(), D11 = zero16();
     float tp0 = 0.f, tp1 = 0.f;
     PROF_BEGIN();
+    TRACE(c, 1, slot);
+    // rows of the panels <= slot-2 of this panel's two columns (the column wave's group 1 of panel slot-2 was the last)
+    if (slot >= 2) {
+        if (!pt_wait(sh, &sh->colrow[j0], slot - 1)) return false;
+        if (has1 && !pt_wait(sh, &sh->colrow[j1], slot - 1)) return false;
+    }
+    PROF_END(c, 10);
     // the chain is the critical path of the sweep: let it win VALU / LDS issue arbitration against the
     // MFMA-bound wave of the other resident workgroup that shares this SIMD
     __builtin_amdgcn_s_setprio(3);
+    TRACE(c, 2, slot);
     chain_kloop<D, KN>(c, p, 0, kwait, D00, D01, D11, tp0, tp1);
+    TRACE(c, 3, slot);
     if (kwait < j0 && !held) {
-        // group 0 of the previous panel is being finished by the column wave in this slot: wait for its rows
-        while (__hip_atomic_load(&sh->g0done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < slot)
-            __builtin_amdgcn_s_sleep(2);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // group 0 of the previous panel is finished by the column wave: wait for its rows
+        PROF_END(c, 0);
+        if (!pt_wait(sh, &sh->g0done, slot)) { __builtin_amdgcn_s_setprio(0); return false; }
         PROF_END(c, 10);
         chain_kloop<D, KN>(c, p, kwait, j0, D00, D01, D11, tp0, tp1);
     }
     if (kwait < j0 && held) {
+        PROF_END(c, 0);
+        if (!pt_wait(sh, &sh->parked, slot)) { __builtin_amdgcn_s_setprio(0); return false; }
+        PROF_END(c, 10);
+        TRACE(c, 4, slot);
         // Rows j0-2, j0-1 of this panel's two columns = group 0 of the previous panel q (both items U-type), whose k-loop the column
         // wave parked in LDS (L.Wh) during the previous slot.  Finish them here (6 block products), store them for
         // everybody else, and use them straight from registers as the last two k-steps of D00 / D01 / D11.
@@ -662,10 +758,17 @@ __device__ __forceinline__ void pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const
         const f32x16 L1 = ldl(c.L.LT + (2 * qpar + 1) * BLK, lane);
         const f32x16 Uq = ldl(c.L.U01 + qpar * BLK, lane);
         f32x16 X0[2], X1[2];
+        f32x16 Wp[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) Wp[n] = ldl(c.L.Wh + n * BLK, lane);
+        // the parking area is free again for the column wave (LDS serves a wave's requests in order: the reads above
+        // are ahead of this store, and the next parked k-loop is written only after the store has been seen)
+        wave_lds_sync();
+        if (lane == 0) __hip_atomic_store(&sh->whfree, slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            const f32x16 W0 = ldl(c.L.Wh + n * BLK, lane);
-            f32x16 W1 = ldl(c.L.Wh + (2 + n) * BLK, lane);
+            const f32x16 W0 = Wp[n];
+            f32x16 W1 = Wp[2 + n];
             X0[n] = zero16();
             mma_blk(X0[n], L0, W0);
             f32x16 T = zero16();
@@ -690,6 +793,14 @@ __device__ __forceinline__ void pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const
         if (lane == 0) __hip_atomic_store(&sh->g0done, slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     PROF_END(c, 0);
+    TRACE(c, 5, slot);
+    // the factor copies of this parity still serve the groups of panel slot-2
+    if (slot >= 2) {
+        if (!pt_wait(sh, &sh->gdone[par], lt_users)) { __builtin_amdgcn_s_setprio(0); return false; }
+        if (lane == 0) __hip_atomic_store(&sh->gdone[par], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        PROF_END(c, 10);
+    }
+    TRACE(c, 6, slot);
     f32x16 S1keep = zero16();
     const int nrow = has1 ? 2 : 1;
     for (int r = 0; r < nrow; ++r) {
@@ -714,6 +825,7 @@ __device__ __forceinline__ void pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const
         PROF_END(c, 2);
         diag_factor(Dd, c.L.Ad, c.L.piv, lane, S1, S2, ls, bad);
         PROF_END(c, 1);
+        TRACE(c, 7 + r, slot);
         stg(c.ws, jr * NB + jr, lane, S1);            // M_jrjr
         stg(c.ws, c.dT0 + jr, lane, S2);              // (L_jr^-1)^T
         stl(c.L.LT + (2 * par + r) * BLK, lane, S2);
@@ -763,7 +875,16 @@ __device__ __forceinline__ void pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const
         }
     }
     __builtin_amdgcn_s_setprio(0);
+    // publish: factors (LDS), diagonal blocks, U_j0j1, M_j1j0, z are in place; the panel's columns are complete
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) {
+        __hip_atomic_store(&sh->colrow[j0], slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (has1) __hip_atomic_store(&sh->colrow[j1], slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&sh->ready, slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     PROF_END(c, 2);
+    TRACE(c, 9, slot);
+    return true;
 }
 
 template <int D>
@@ -777,102 +898,149 @@ __device__ __forceinline__ Panel<D> make_panel(int NB, int pi, bool want_m) {
     return p;
 }
 
-// Software-pipelined sweep with ONE workgroup barrier per panel.  In slot s
-//   wave 0 ("chain")  : diagonal chain of panel s, then helps with the bulk;
-//   wave 1 ("column") : the two block columns the NEXT chain needs: rows of group 0 of panel s-1 (its
-//                       k-loop was already run in slot s-1 and is held in registers) -> flag for the chain,
-//                       then group 1 of panel s-1, then other bulk, finally the k-loop of group 0 of
-//                       panel s (held across the barrier);
-//   waves 2,3 ("bulk"): groups >= 2 of panel s-1, pulled from an LDS queue.
-// The dependent chain per panel is therefore only: 6 block products (rows of group 0) -> 2 k-steps + two
-// 32x32 factorisations; everything else overlaps it.
+// Dataflow sweep: no workgroup barrier between panels; the waves meet through flags in LDS (Shared):
+//   ready      panels whose diagonal chain is complete (factors published, diagonal blocks / U_j0j1 / M_j1j0 / z in place)
+//   colrow[c]  panels whose rows of block column c are in memory (a group of panel s needs colrow >= s for its columns)
+//   parked / whfree   hand-over of the run-ahead k-loop of group 0 (L.Wh) from the column wave to the chain and back
+//   g0done     rows of panel s-1 of the columns of panel s are in memory (chain -> column wave, or the reverse in the tail)
+//   gdone[par] groups of the panel of that parity that have finished with its factor copies (the chain of panel s+2 reuses them)
+//   wave 0 ("chain")  : the diagonal chains of all panels back to back, each as soon as its two columns are there;
+//   wave 1 ("column") : per panel s the work the next chains wait for -- group 0 (tail only) and group 1 of panel s-1, then
+//                       the k-loop of group 0 of panel s run ahead and parked for the chain;
+//   other waves ("bulk"): groups >= 2 of all panels from ONE queue in panel-major order; waves 0 and 1 join when done.
+// The dependent path per panel is: 6 block products (rows of group 0) -> 2 k-steps + two 32x32 factorisations; nobody
+// waits for anything else, so the second workgroup of the CU fills whatever a wave leaves idle.
+// Results do not depend on which wave runs a group: each group is the same arithmetic and per-column updates are ordered
+// by colrow.
+// groups of panel q that go through pt_run_group (group 0 is finished by the next chain when it was parked)
+template <int D>
+__device__ __forceinline__ int pt_lt_users(const Panel<D>& q) { return ((q.nItems + 1) >> 1) - (q.nU >= 2 ? 1 : 0); }
+
+// one group of panel q (index sq): wait for its columns, k-loop, wait for the panel's factors, row solves, publish
+template <int D, int KN>
+__device__ __forceinline__ bool pt_run_group(const Ctx<D, KN>& c, const Panel<D>& q, int sq, int g) {
+    Shared* sh = shared_state();
+    PROF_BEGIN();
+    TRACE(c, 20, sq * 16 + g);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int e = 2 * g + n;
+        if (e < q.nItems && !pt_wait(sh, &sh->colrow[pt_item_col(q, e)], sq)) return false;
+    }
+    // ... and of the panel's own two columns (their rows of panel sq-1 come last: group 0 of that panel)
+    if (sq >= 1 && !pt_wait(sh, &sh->g0done, sq)) return false;
+    PROF_END(c, 3);
+    TRACE(c, 21, sq * 16 + g);
+    f32x16 W[4];
+    pt_group_kloop<D, KN>(c, q, g, W);
+    PROF_END(c, 4);
+    TRACE(c, 22, sq * 16 + g);
+    // only the row solves need the panel's own factors: the k-loop above ran while its chain may still be at work
+    if (!pt_wait(sh, &sh->ready, sq + 1)) return false;
+    PROF_END(c, 3);
+    TRACE(c, 24, sq * 16 + g);
+    pt_group_row<D, KN>(c, q, g, 0, sq & 1, W);
+    if (q.has1) pt_group_row<D, KN>(c, q, g, 1, sq & 1, W);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (c.lane == 0) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int e = 2 * g + n;
+            if (e < q.nItems) __hip_atomic_store(&sh->colrow[pt_item_col(q, e)], sq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __hip_atomic_fetch_add(&sh->gdone[sq & 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    PROF_END(c, 5);
+    TRACE(c, 23, sq * 16 + g);
+    return true;
+}
+
 template <int D, int KN>
 __device__ __forceinline__ void phase_pt(Ctx<D, KN>& c, const bool want_m) {
     Shared* sh = shared_state();
     const int NB = c.NB, w = c.w;
     const int NP = (NB + 1) >> 1;
-    if (c.tid == 0) { sh->logdet = 0.0; sh->fail = 0; sh->g0done = 0; sh->gnext[0] = 2; sh->gnext[1] = 2; }
+    if (c.tid == 0) {
+        sh->logdet = 0.0; sh->fail = 0; sh->g0done = 0; sh->ready = 0; sh->parked = 0; sh->whfree = 0;
+        sh->gdone[0] = 0; sh->gdone[1] = 0; sh->qhead = 0;
+    }
+    for (int idx = c.tid; idx < NB; idx += NT) sh->colrow[idx] = 0;
     for (int idx = c.tid; idx < c.Npad; idx += NT) lds_f[c.L.alpha + idx] = 0.f;
     __syncthreads();
-    bool held = false;          // wave 1: LDS (L.Wh) holds the finished k-loop of group 0 of the current panel
-    for (int s = 0; s <= NP; ++s) {
-        const bool chain_busy = s < NP;                 // wave 0 runs the chain of panel s first
-        if (chain_busy && w == 0) {
-            if (c.lane == 0) sh->gnext[(s + 1) & 1] = 2;     // queue head of the NEXT slot (groups 0,1: column wave)
-            Panel<D> p = make_panel<D>(NB, s, want_m);
+    bool ok = true;
+    if (w == 0) {
+        for (int s = 0; s < NP && ok; ++s) {
+            const Panel<D> p = make_panel<D>(NB, s, want_m);
             const Panel<D> q = make_panel<D>(NB, s > 0 ? s - 1 : 0, want_m);
             const int kwait = (s > 0) ? (p.j0 - 2) : p.j0;
-            pt_chain<D, KN>(c, p, q, want_m, s & 1, kwait, s, held);
+            const bool held = (s > 0) && (q.nU >= 2);
+            const int users = (s >= 2) ? pt_lt_users<D>(make_panel<D>(NB, s - 2, want_m)) : 0;
+            ok = pt_chain<D, KN>(c, p, q, want_m, s & 1, kwait, s, held, users);
+            if (ok && __hip_atomic_load(&sh->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) ok = false;
         }
-        PROF_BEGIN();
-        if (s >= 1) {
-            const Panel<D> q = make_panel<D>(NB, s - 1, want_m);
-            const int nGroups = (q.nItems + 1) >> 1;
-            const int par = (s - 1) & 1;
-            f32x16 W[4];
-            if (w == 1) {
-                // group 0: while a chain is running the chain wave finishes it from the parked k-loop
-                if (nGroups > 0 && !(chain_busy && held)) {
-                    if (held) {
+    } else if (w == 1) {
+        for (int s = 0; s < NP && ok; ++s) {
+            if (s >= 1) {
+                const Panel<D> q = make_panel<D>(NB, s - 1, want_m);
+                const int nGroups = (q.nItems + 1) >> 1;
+                if (ok && nGroups > 0 && q.nU < 2) {
+                    // tail: group 0 was not parked; the chain of panel s waits for these rows
+                    ok = pt_run_group<D, KN>(c, q, s - 1, 0);
+                    if (ok && c.lane == 0) __hip_atomic_store(&sh->g0done, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (ok && nGroups > 1) ok = pt_run_group<D, KN>(c, q, s - 1, 1);
+            }
+            if (ok && s < NP) {
+                // run ahead: k-loop of group 0 of panel s (the columns of the next chain), parked in LDS for that chain
+                const Panel<D> pn = make_panel<D>(NB, s, want_m);
+                if (pn.nU >= 2) {
+                    PROF_BEGIN();
+                    ok = pt_wait(sh, &sh->colrow[pn.j1 + 1], s) && pt_wait(sh, &sh->colrow[pn.j1 + 2], s);
+                    // rows of panel s-1 of the columns j0(s), j1(s): written by the chain of panel s (or above, in the tail)
+                    if (ok && s >= 1) ok = pt_wait(sh, &sh->g0done, s);
+                    if (ok) ok = pt_wait(sh, &sh->whfree, s);
+                    PROF_END(c, 3);
+                    TRACE(c, 30, s);
+                    if (ok) {
+                        f32x16 W[4];
+                        pt_group_kloop<D, KN>(c, pn, 0, W);
 #pragma unroll
-                        for (int n = 0; n < 4; ++n) W[n] = ldl(c.L.Wh + n * BLK, c.lane);
-                    } else {
-                        pt_group_kloop<D, KN>(c, q, 0, W);
-                    }
-                    pt_group_row<D, KN>(c, q, 0, 0, par, W);
-                    if (q.has1) pt_group_row<D, KN>(c, q, 0, 1, par, W);
-                    if (chain_busy) {
-                        // not parked (odd NB tail): the chain of this slot waits for these rows
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        if (c.lane == 0) __hip_atomic_store(&sh->g0done, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        for (int n = 0; n < 4; ++n) stl(c.L.Wh + n * BLK, c.lane, W[n]);
+                        wave_lds_sync();
+                        if (c.lane == 0) __hip_atomic_store(&sh->parked, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        PROF_END(c, 4);
+                        TRACE(c, 31, s);
                     }
                 }
-                PROF_END(c, 5);
-                if (nGroups > 1) {
-                    pt_group_kloop<D, KN>(c, q, 1, W);
-                    PROF_END(c, 4);
-                    pt_group_row<D, KN>(c, q, 1, 0, par, W);
-                    if (q.has1) pt_group_row<D, KN>(c, q, 1, 1, par, W);
-                    PROF_END(c, 5);
-                }
-            }
-            // the column wave already carries two groups' worth of fixed work per slot: while a chain is running
-            // it leaves the queue to the others
-            int g = (w == 1 && chain_busy) ? nGroups : wave_pull(&sh->gnext[s & 1], c.lane);
-            while (g < nGroups) {
-                pt_group_kloop<D, KN>(c, q, g, W);
-                PROF_END(c, 4);
-                pt_group_row<D, KN>(c, q, g, 0, par, W);
-                if (q.has1) pt_group_row<D, KN>(c, q, g, 1, par, W);
-                PROF_END(c, 5);
-                g = wave_pull(&sh->gnext[s & 1], c.lane);
             }
         }
-        if (w == 1 && chain_busy) {
-            // run ahead: k-loop of group 0 of panel s (the columns of the next chain); it only needs rows
-            // < j0(s), all of which are in memory (the newest ones were written by this very wave)
-            const Panel<D> pn = make_panel<D>(NB, s, want_m);
-            if (pn.nU >= 2) {
-                if (s >= 1 && held) {
-                    // rows of panel s-1 for the columns j0(s), j1(s) were written by the chain wave in this slot
-                    while (__hip_atomic_load(&sh->g0done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < s)
-                        __builtin_amdgcn_s_sleep(2);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                }
-                f32x16 W[4];
-                pt_group_kloop<D, KN>(c, pn, 0, W);
-#pragma unroll
-                for (int n = 0; n < 4; ++n) stl(c.L.Wh + n * BLK, c.lane, W[n]);
-                PROF_END(c, 4);
-            }
-        }
-        // every wave tracks whether group 0 of panel s has been run ahead and parked
-        held = chain_busy && (make_panel<D>(NB, s, want_m).nU >= 2);
-        __syncthreads();
-        PROF_END(c, 3);
-        if (sh->fail) break;
     }
+    // the bulk queue: groups >= 2 of every panel, panel-major; nobody waits for the last panel's groups 0 and 1, so they
+    // are queued as well
+    {
+        int sq = 0, base = 0;
+        Panel<D> q = make_panel<D>(NB, 0, want_m);
+        int g0 = (NP == 1) ? 0 : 2;
+        int nq = max(0, ((q.nItems + 1) >> 1) - g0);
+        while (ok) {
+            const int idx = wave_pull(&sh->qhead, c.lane);
+            while (sq < NP && idx >= base + nq) {
+                base += nq;
+                ++sq;
+                if (sq < NP) {
+                    q = make_panel<D>(NB, sq, want_m);
+                    g0 = (sq == NP - 1) ? 0 : 2;
+                    nq = max(0, ((q.nItems + 1) >> 1) - g0);
+                }
+            }
+            if (sq >= NP) break;
+            TRACE(c, 50, sq);
+            ok = pt_run_group<D, KN>(c, q, sq, g0 + idx - base);
+        }
+    }
+    TRACE(c, 60, 0);
     __syncthreads();
+    TRACE(c, 61, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -902,6 +1070,7 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
             PROF_BEGIN();
             const int b1 = b0 + 1;
             const bool hasb1 = b1 <= bmax;
+            TRACE(c, 70, a0);
             const bool use01 = hasb1 && b1 <= a0;      // (a0, b1) is a lower block (false on the diagonal group)
             f32x16 acc[4];
 #pragma unroll
@@ -919,6 +1088,24 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
                 mma_blk(acc[0], A0, B0);
                 if (use01) mma_blk(acc[1], A0, B1);
                 A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
+#ifdef GPSAT_EXP_INPLACE
+                for (int cc = a1; cc < NB; ++cc) {
+                    // in-place operand refill, as in pt_group_kloop
+                    const int cn = min(cc + 1, NB - 1);
+                    nB0 = ldg(c.ws, cn * NB + b0, lane);
+                    mma_blk(acc[0], A0, B0);
+                    if (use01) mma_blk(acc[1], A0, B1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    A0 = ldg(c.ws, cn * NB + a0, lane);
+                    if (hasb1) mma_blk(acc[3], A1, B1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    B1 = ldg(c.ws, hasb1 ? cn * NB + b1 : c.zb, lane);
+                    mma_blk(acc[2], A1, B0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    A1 = ldg(c.ws, cn * NB + a1, lane);
+                    B0 = nB0;
+                }
+#else
                 for (int cc = a1; cc < NB; ++cc) {
                     nA0 = A0; nA1 = A1; nB0 = B0; nB1 = B1;
                     if (cc + 1 < NB) {
@@ -934,6 +1121,7 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
                     if (hasb1) mma_blk(acc[3], A1, B1);
                     A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
                 }
+#endif
             } else {
                 mma_blk(acc[0], A0, B0);
                 if (use01) mma_blk(acc[1], A0, B1);
@@ -946,6 +1134,7 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
                 if (hasb1) contract<D, KN>(c, acc[3], a1, b1, (a1 == b1) ? 1.f : 2.f, accl, accsf, accsn);
             }
             PROF_END(c, 7);
+            TRACE(c, 71, a0);
         }
     }
     // wave reduction (doubles), then across waves through LDS
@@ -1014,6 +1203,9 @@ __device__ __forceinline__ void evaluate(Ctx<D, KN>& c, bool want_grad) {
         for (int d = 0; d < D; ++d) lds_f[c.L.xsc + d * c.Npad + idx] = lds_f[c.L.xs + d * c.Npad + idx] * invl[d];
     }
     __syncthreads();
+    // (Experiment E17: not joining the sweep before the gradient phase -- K^-1 groups started per wave as soon as their
+    // block columns were final -- removed the idle tail of the sweep and changed nothing: the other workgroup of the CU
+    // already fills it.)
     phase_pt<D, KN>(c, want_grad);
     if (sh->fail) {
         if (c.tid == 0) { sh->nll = __builtin_inf(); for (int i = 0; i < D + 2; ++i) sh->gth[i] = 0.0; }
@@ -1180,7 +1372,11 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
     c.zb = (int)(A.ws_stride / BLK) - 1;            // last block of the workgroup's workspace: zeros
     for (int i = c.tid; i < BLK; i += NT) c.ws[(size_t)c.zb * BLK + i] = 0.f;
     c.prof = sh->prof;
+    c.trace = nullptr;
 #ifdef GPSAT_PROFILE
+    if (blockIdx.x == 0 && A.prof) c.trace = A.prof + 64;
+    if (c.tid < NW) sh->tcnt[c.tid] = 0;
+    int prof_ntiles = 0;                          // the evaluations of the THIRD tile of workgroup 0 are traced
     if (c.tid < NW * 16) sh->prof[c.tid] = 0ull;
     const unsigned long long prof_k0 = __builtin_amdgcn_s_memtime(), prof_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1194,6 +1390,10 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
         __syncthreads();
         const int slot = sh->tile;
         if (slot >= A.T) break;
+#ifdef GPSAT_PROFILE
+        if (c.tid == 0) sh->tron = (prof_ntiles == 2);
+        ++prof_ntiles;
+#endif
         const int t = A.order[slot];
         const long long o0 = A.obs_off[t], o1 = A.obs_off[t + 1];
         const long long p0 = A.pred_off[t], p1 = A.pred_off[t + 1];

@@ -37,10 +37,22 @@ struct Shared {
     int box[HMAX];
     int fail, done, status, n_eval, n_eval_opt, iter, phase, want_grad;
     int tile;
-    int g0done;                 // slot index up to which group 0 of the previous panel is in memory
-    int gnext[2];               // dynamic group queue heads of the PT slots (alternating) 
+    // flags of the Cholesky / inverse sweep (phase_pt of the fp32 kernels; the fp64 kernels use g0done and gnext)
+    int g0done;                 // panel index up to which group 0 of the previous panel is in memory
+    int gnext[2];               // fp64 kernels: dynamic group queue heads of the PT slots (alternating)
+#ifdef GPSAT_PT_MAXNB
+    int ready, parked, whfree;  // panels: chain complete / group-0 k-loop parked / parked k-loop consumed
+    int gdone[2];               // groups of the panel of that parity that are finished
+    int qhead;                  // bulk group queue head (all panels)
+    int colrow[GPSAT_PT_MAXNB]; // per block column: panels whose rows are in memory
+#endif
     int gradnext;               // dynamic group queue head of the gradient phase
-    unsigned long long prof[NW * 16];
+#ifdef GPSAT_PROFILE
+    unsigned long long prof[NW * 16];      // diagnostic build: cycle counters per wave and code segment
+    int tcnt[NW], tron;                    // event trace (workgroup 0): entries per wave, on/off
+#else
+    unsigned long long prof[1];
+#endif
 };
 
 
