@@ -60,7 +60,7 @@ struct gpsat_handle {
     char name[256] = {0};
     double last_kernel_ms = 0.0, last_total_ms = 0.0;
     // device buffers (grown lazily, owned by the handle)
-    DevBuf meta_i64, meta_f64, meta_misc, out_f64, out_i32, bulk_in, bulk_out, ws, prof;
+    DevBuf meta_i64, meta_f64, meta_misc, out_f64, out_i32, bulk_in, bulk_out, ws, prof, ring, state;
     DevBuf sel_pts, sel_refs, sel_cnt, sel_idx, sel_box;
     unsigned long long prof_host[64 + 8 * 1024] = {0};     // counters + event trace (diagnostic build)
 };
@@ -126,7 +126,7 @@ int gpsat_destroy(gpsat_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->meta_i64.release(); h->meta_f64.release(); h->meta_misc.release(); h->out_f64.release();
-    h->out_i32.release(); h->bulk_in.release(); h->bulk_out.release(); h->ws.release(); h->prof.release();
+    h->out_i32.release(); h->bulk_in.release(); h->bulk_out.release(); h->ws.release(); h->prof.release(); h->ring.release(); h->state.release();
     h->sel_pts.release(); h->sel_refs.release(); h->sel_cnt.release(); h->sel_idx.release(); h->sel_box.release();
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -263,7 +263,45 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     HIP_TRY(hipMemcpyAsync(d_train, b->trainable, (size_t)H, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(d_order, order.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, h->stream));
 
+    // ---- time slicing of the optimisation (fp32): with few tiles per resident workgroup, whole tiles as the scheduling unit
+    // leave the GPU half empty while the last ones finish (4096 tiles on 512 workgroups: 8 % of the launch).  Tiles of
+    // similar cost are therefore served in slices of ~4 evaluations of a 512-point tile; a batch whose largest tile
+    // dominates keeps the largest-first run-to-completion order (its critical path must not wait in a queue).
+    int seg_cost = 0;
+    if (!f64 && b->optimiser != GPSAT_OPT_NONE && b->max_iter > 0) {
+        double sum_cost = 0.0, max_cost = 0.0;
+        for (int t = 0; t < T; ++t) {
+            const double nb = (double)((b->obs_off[t + 1] - b->obs_off[t] + 31) / 32);
+            sum_cost += nb * nb * nb;
+            max_cost = std::max(max_cost, nb * nb * nb);
+        }
+        const double tiles_per_wg = (double)T / grid;
+        if (T > grid && max_cost * 4.0 * grid <= sum_cost && tiles_per_wg <= 64.0) seg_cost = 4 * 16 * 16 * 16;
+        // developer / tests: slice length in NB^3 units (0 = off, 1 = every evaluation), whatever the batch looks like
+        if (const char* e = std::getenv("GPSAT_DEBUG_SEG")) seg_cost = std::max(0, std::atoi(e));
+    }
+    unsigned long long* d_ring = nullptr; int* d_ring_ctl = nullptr; unsigned* d_state = nullptr;
+    int ring_mask = 0;
+    const int state_words = w8 ? gpsat::state_words_w8() : gpsat::state_words();
+    if (seg_cost > 0) {
+        size_t cap = 1; while (cap < (size_t)T + (size_t)grid + 1) cap <<= 1;
+        ring_mask = (int)(cap - 1);
+        if ((rc = h->ring.reserve(cap * sizeof(unsigned long long) + 256))) return rc;
+        if ((rc = h->state.reserve((size_t)T * state_words * sizeof(unsigned)))) return rc;
+        d_ring_ctl = static_cast<int*>(h->ring.p);
+        d_ring = reinterpret_cast<unsigned long long*>(static_cast<char*>(h->ring.p) + 256);
+        d_state = static_cast<unsigned*>(h->state.p);
+        std::vector<unsigned long long> init(cap, 0ull);
+        for (int i = 0; i < T; ++i) init[i] = ((unsigned long long)(i + 1) << 32) | (unsigned)order[i];
+        int ctl[64] = {0};
+        ctl[16] = T; ctl[32] = T;
+        HIP_TRY(hipMemcpyAsync(d_ring_ctl, ctl, sizeof(ctl), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(d_ring, init.data(), cap * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));          // `init` and `ctl` are stack / local host memory
+    }
+
     gpsat::KernelArgs a;
+    a.ring = d_ring; a.ring_ctl = d_ring_ctl; a.state = d_state; a.ring_mask = ring_mask; a.state_words = state_words; a.seg_cost = seg_cost;
     a.T = T; a.kernel = b->kernel; a.optimiser = b->optimiser; a.max_iter = b->max_iter;
     a.max_ls = b->max_ls > 0 ? b->max_ls : 20;                                 // SciPy L-BFGS-B maxls
     a.NBmax = NBmax;
@@ -317,8 +355,11 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
 #ifdef GPSAT_PROFILE
     HIP_TRY(hipMemcpyAsync(h->prof_host, h->prof.p, sizeof(h->prof_host), hipMemcpyDeviceToHost, h->stream));
 #endif
+    int unfinished = 0;
+    if (seg_cost > 0) HIP_TRY(hipMemcpyAsync(&unfinished, d_ring_ctl + 32, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (unfinished != 0) return fail(GPSAT_EHIP, "time-sliced tile queue ended with " + std::to_string(unfinished) + " unfinished tiles");
     float km = 0.f, tm = 0.f;
     HIP_TRY(hipEventElapsedTime(&km, h->ev[1], h->ev[2]));
     HIP_TRY(hipEventElapsedTime(&tm, h->ev[0], h->ev[3]));

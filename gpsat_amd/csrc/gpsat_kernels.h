@@ -37,6 +37,13 @@ struct KernelArgs {
     const long long* cov_off;     // [T+1] element offsets into f_cov, or nullptr
     float* f_cov;                 // per tile P x P posterior covariance, or nullptr
     int PCmax;                    // max prediction chunks per tile (only used with f_cov)
+    // time slicing of the optimisation (fp32 kernels; seg_cost = 0: every tile runs to completion from `queue`):
+    // tiles are served from a ring; after ~seg_cost / NB^3 evaluations an unfinished tile's optimiser state is saved and the
+    // tile goes to the back of the ring, so that all tiles of a homogeneous batch finish together instead of leaving a tail
+    unsigned long long* ring;     // [ring_mask + 1] entries (sequence + 1) << 32 | resumed << 31 | tile; first T preset
+    int* ring_ctl;                // [0] pop counter, [16] push counter (preset T), [32] unfinished tiles (preset T)
+    unsigned* state;              // [T][state_words] saved optimiser state (the kernel's Shared struct)
+    int ring_mask, state_words, seg_cost;
 };
 
 size_t shared_bytes(int D, int NBmax);
@@ -50,10 +57,12 @@ size_t workspace_doubles_per_wg_f64_w4(int NBmax, int PCcov);
 hipError_t launch_tiles_f64_w4(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream);
 size_t workspace_floats_per_wg(int NBmax, int PCcov);     // PCcov: prediction chunks kept for f_cov (0 = none)
 hipError_t launch_tiles(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream);
+int state_words();                                        // 32-bit words of saved optimiser state per tile (time slicing)
 // 8-wave build of the same kernels (gpsat_kernels.hip -DGPSAT_W8): used when a workgroup needs more than half of the LDS
 size_t shared_bytes_w8(int D, int NBmax);
 size_t workspace_floats_per_wg_w8(int NBmax, int PCcov);
 hipError_t launch_tiles_w8(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream);
+int state_words_w8();
 
 #define GPSAT_SEL_MAXCRIT 4
 

@@ -591,6 +591,42 @@ __device__ __forceinline__ void pt_group_kloop(const Ctx<D, KN>& c, const Panel<
             B0 = nB0;
         }
     }
+#elif defined(GPSAT_EXP_UNROLL2)  // experiment E12': two k-steps per trip, the operand sets swap roles (no copies)
+    if (kmin < j0) {
+        f32x16 A0 = ldg(c.ws, kmin * NB + j0, lane);
+        f32x16 A1 = ldg(c.ws, p.has1 ? kmin * NB + p.j1 : c.zb, lane);
+        f32x16 B0 = ldg(c.ws, (kmin >= ks0) ? kmin * NB + c0 : c.zb, lane);
+        f32x16 B1 = ldg(c.ws, (kmin >= ks1) ? kmin * NB + c1 : c.zb, lane);
+        int k = kmin;
+        for (; k + 1 < j0; k += 2) {
+            const int kn = k + 1;
+            const f32x16 Y0 = ldg(c.ws, kn * NB + j0, lane);
+            const f32x16 Y1 = ldg(c.ws, p.has1 ? kn * NB + p.j1 : c.zb, lane);
+            const f32x16 Z0 = ldg(c.ws, (kn >= ks0) ? kn * NB + c0 : c.zb, lane);
+            const f32x16 Z1 = ldg(c.ws, (kn >= ks1) ? kn * NB + c1 : c.zb, lane);
+            mma_blk(W[0], A0, B0);
+            mma_blk(W[1], A0, B1);
+            mma_blk(W[2], A1, B0);
+            mma_blk(W[3], A1, B1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int km = min(k + 2, j0 - 1);
+            A0 = ldg(c.ws, km * NB + j0, lane);
+            A1 = ldg(c.ws, p.has1 ? km * NB + p.j1 : c.zb, lane);
+            B0 = ldg(c.ws, (km >= ks0) ? km * NB + c0 : c.zb, lane);
+            B1 = ldg(c.ws, (km >= ks1) ? km * NB + c1 : c.zb, lane);
+            mma_blk(W[0], Y0, Z0);
+            mma_blk(W[1], Y0, Z1);
+            mma_blk(W[2], Y1, Z0);
+            mma_blk(W[3], Y1, Z1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (k < j0) {
+            mma_blk(W[0], A0, B0);
+            mma_blk(W[1], A0, B1);
+            mma_blk(W[2], A1, B0);
+            mma_blk(W[3], A1, B1);
+        }
+    }
 #else
     if (kmin < j0) {
         f32x16 A0 = ldg(c.ws, kmin * NB + j0, lane);
@@ -1105,6 +1141,36 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
                     A1 = ldg(c.ws, cn * NB + a1, lane);
                     B0 = nB0;
                 }
+#elif defined(GPSAT_EXP_UNROLL2)
+                int cc = a1;
+                for (; cc + 1 < NB; cc += 2) {
+                    const int cn = cc + 1;
+                    nA0 = ldg(c.ws, cn * NB + a0, lane);
+                    nA1 = ldg(c.ws, cn * NB + a1, lane);
+                    nB0 = ldg(c.ws, cn * NB + b0, lane);
+                    nB1 = ldg(c.ws, hasb1 ? cn * NB + b1 : c.zb, lane);
+                    mma_blk(acc[0], A0, B0);
+                    if (use01) mma_blk(acc[1], A0, B1);
+                    mma_blk(acc[2], A1, B0);
+                    if (hasb1) mma_blk(acc[3], A1, B1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int cm = min(cc + 2, NB - 1);
+                    A0 = ldg(c.ws, cm * NB + a0, lane);
+                    A1 = ldg(c.ws, cm * NB + a1, lane);
+                    B0 = ldg(c.ws, cm * NB + b0, lane);
+                    B1 = ldg(c.ws, hasb1 ? cm * NB + b1 : c.zb, lane);
+                    mma_blk(acc[0], nA0, nB0);
+                    if (use01) mma_blk(acc[1], nA0, nB1);
+                    mma_blk(acc[2], nA1, nB0);
+                    if (hasb1) mma_blk(acc[3], nA1, nB1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (cc < NB) {
+                    mma_blk(acc[0], A0, B0);
+                    if (use01) mma_blk(acc[1], A0, B1);
+                    mma_blk(acc[2], A1, B0);
+                    if (hasb1) mma_blk(acc[3], A1, B1);
+                }
 #else
                 for (int cc = a1; cc < NB; ++cc) {
                     nA0 = A0; nA1 = A1; nB0 = B0; nB1 = B1;
@@ -1344,6 +1410,34 @@ __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const float* __restr
 // ---------------------------------------------------------------------------------------------
 // the persistent kernel
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// time slicing (KernelArgs::seg_cost > 0): the tiles circulate through a ring in device memory.  An entry is
+// (sequence + 1) << 32 | resumed << 31 | tile; slot s lives at s & ring_mask.  The ring is larger than the number of tiles
+// plus the number of workgroups, so a slot is never rewritten before the workgroup that claimed it has read it.
+// One thread per workgroup calls these.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ring_pop(const KernelArgs& A) {
+    const unsigned s = (unsigned)__hip_atomic_fetch_add(&A.ring_ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long* e = A.ring + (s & (unsigned)A.ring_mask);
+    for (int spins = 0;; ++spins) {
+        // relaxed polling: an agent-scope acquire invalidates the XCD's L2 each time, which every other workgroup pays for;
+        // the one acquire a resumed tile needs is the fence before its state is read (gp_tile_kernel)
+        const unsigned long long v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(v >> 32) == s + 1u) return (int)(unsigned)v;
+        // nothing there yet: either a tile will be pushed back, or every tile is finished
+        if (__hip_atomic_load(&A.ring_ctl[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) return -1;
+        // never reached by design (minutes of polling): a lost entry must not hang the GPU; the host sees unfinished tiles
+        if (spins > (1 << 25)) return -1;
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
+__device__ __forceinline__ void ring_push(const KernelArgs& A, int tile) {
+    const unsigned s = (unsigned)__hip_atomic_fetch_add(&A.ring_ctl[16], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long v = ((unsigned long long)(s + 1u) << 32) | 0x80000000ull | (unsigned)tile;
+    __hip_atomic_store(A.ring + (s & (unsigned)A.ring_mask), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int D, int KN>
 __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelArgs A) {
     constexpr int H = D + 2;
@@ -1384,17 +1478,26 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
     o.optimiser = A.optimiser; o.max_iter = A.max_iter; o.max_ls = A.max_ls; o.want_grad_out = A.grad != nullptr;
     o.ftol = A.ftol; o.gtol = A.gtol; o.adam_lr = A.adam_lr; o.noise_rel = A.noise_rel;
 
+    const bool sliced = A.seg_cost > 0;
     for (;;) {
         __syncthreads();
-        if (c.tid == 0) sh->tile = atomicAdd(A.queue, 1);
+        if (c.tid == 0) {
+            if (sliced) {
+                sh->tile = ring_pop(A);
+            } else {
+                const int slot = atomicAdd(A.queue, 1);
+                sh->tile = slot < A.T ? A.order[slot] : -1;
+            }
+        }
         __syncthreads();
-        const int slot = sh->tile;
-        if (slot >= A.T) break;
+        const int entry = sh->tile;
+        if (entry == -1) break;
 #ifdef GPSAT_PROFILE
         if (c.tid == 0) sh->tron = (prof_ntiles == 2);
         ++prof_ntiles;
 #endif
-        const int t = A.order[slot];
+        const int t = entry & 0x7fffffff;
+        const bool resumed = entry < 0;           // bit 31: the tile's optimiser state is in A.state
         const long long o0 = A.obs_off[t], o1 = A.obs_off[t + 1];
         const long long p0 = A.pred_off[t], p1 = A.pred_off[t + 1];
         c.N = (int)(o1 - o0);
@@ -1437,6 +1540,7 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
                     A.f_cov[A.cov_off[t] + e] = sf2 * kf;
                 }
             }
+            if (sliced && c.tid == 0) __hip_atomic_fetch_add(&A.ring_ctl[32], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             continue;
         }
         // ---- stage tile data into LDS (SoA coordinates), zero padding
@@ -1448,7 +1552,16 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
             lds_f[c.L.z + idx] = 0.f;
             lds_f[c.L.alpha + idx] = 0.f;
         }
-        if (c.tid == 0) {
+        if (resumed) {
+            // The state was written by another workgroup, possibly on another XCD (whose L2 is not coherent with this one).
+            // It travels through agent-scope atomic word accesses, which go to memory past the caches: no cache-wide
+            // write-back / invalidate (an agent-scope fence costs every workgroup of the XCD its L2 contents).  The writer's
+            // stores had completed (vmcnt 0 + barrier) before it published the ring entry this workgroup has seen.
+            const unsigned* src = A.state + (size_t)t * A.state_words;
+            unsigned* dst = reinterpret_cast<unsigned*>(sh);
+            for (int i = c.tid; i < A.state_words; i += NT)
+                dst[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (c.tid == 0) {
             sh->n_eval = 0; sh->n_eval_opt = 0; sh->status = 5; sh->iter = 0; sh->hist_n = 0; sh->hist_pos = 0;
             sh->last_dec = 1e300;
             sh->fail = 0;
@@ -1470,11 +1583,26 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
         __syncthreads();
 
         // ================= evaluate / advance loop (one inlined evaluate call site) =================
-        for (;;) {
+        const int seg_evals = sliced ? max(1, A.seg_cost / (NB * NB * NB)) : 0x7fffffff;
+        bool suspended = false;
+        for (int nseg = 1;; ++nseg) {
             evaluate<D, KN>(c, sh->want_grad != 0);
             if (c.tid == 0) opt_advance(sh, H, o);
             __syncthreads();
             if (sh->phase == PH_EXIT) break;
+            // time slice used up while the optimiser goes on (the final evaluation + prediction are never split off:
+            // prediction needs this workgroup's factorisation)
+            if (nseg >= seg_evals && sh->phase != PH_FINAL) { suspended = true; break; }
+        }
+        if (suspended) {
+            unsigned* dst = A.state + (size_t)t * A.state_words;
+            const unsigned* src = reinterpret_cast<const unsigned*>(sh);
+            for (int i = c.tid; i < A.state_words; i += NT)
+                __hip_atomic_store(&dst[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // every wave: its stores have completed (vmcnt 0)
+            __syncthreads();
+            if (c.tid == 0) ring_push(A, t);
+            continue;
         }
 
         // ================= outputs + prediction from the factorisation at the accepted parameters
@@ -1505,6 +1633,7 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
                     for (long long q = A.cov_off[t] + c.tid; q < A.cov_off[t + 1]; q += NT) A.f_cov[q] = __builtin_nanf("");
             }
         }
+        if (sliced && c.tid == 0) __hip_atomic_fetch_add(&A.ring_ctl[32], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #ifdef GPSAT_PROFILE
     __syncthreads();
@@ -1564,6 +1693,7 @@ hipError_t launch_tiles(int D, const KernelArgs& a, int grid, size_t smem, hipSt
 }  // namespace GPSAT_VNS
 
 size_t GPSAT_VFN(shared_bytes)(int D, int NBmax) { return GPSAT_VNS::shared_bytes(D, NBmax); }
+int GPSAT_VFN(state_words)() { return GPSAT_VNS::SHARED_FLOATS; }
 size_t GPSAT_VFN(workspace_floats_per_wg)(int NBmax, int PCcov) { return GPSAT_VNS::workspace_floats_per_wg(NBmax, PCcov); }
 hipError_t GPSAT_VFN(launch_tiles)(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream) {
     return GPSAT_VNS::launch_tiles(D, a, grid, smem, stream);
