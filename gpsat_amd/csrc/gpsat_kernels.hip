@@ -73,6 +73,7 @@ namespace GPSAT_VNS {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));       // v_pk_*_f32: two fp32 operations per VALU issue slot
 
 // The whole LDS of a workgroup.  Everything in LDS is addressed as lds_f[offset] so that the compiler
 // always knows the address space (ds_* instructions, never flat_*).
@@ -207,6 +208,9 @@ __device__ __forceinline__ void kfun(float r2, float& kf, float& gg) {
     }
 }
 
+#ifndef GPSAT_EXP_UNROLL2
+#define GPSAT_EXP_UNROLL2 0      // experiment: k-loops two steps per trip without operand copies (1: sweep, 2: K^-1 phase)
+#endif
 #ifndef GPSAT_EXP_ABL
 #define GPSAT_EXP_ABL 0          // developer ablations (scripts/eval_bench.py); 0 in every shipped build
 #endif
@@ -249,20 +253,26 @@ __device__ __forceinline__ f32x16 kblock_t(const Ctx<D, KERN>& c, int bi, int bj
     f32x16 out;
     if (bi != bj && 32 * bi + 32 <= c.N && 32 * bj + 32 <= c.N) {
         // interior off-diagonal block (most of them): no padding, no diagonal -- nothing to mask
+        // row pairs in packed fp32 (same operations and rounding as the scalar form, half the issue slots)
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
             const int p0 = 32 * bi + 8 * qq + 4 * c.h;
-            float r2[4];
+            f32x2 r2[2];
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                f32x4 xp = *reinterpret_cast<const f32x4*>(lds_f + c.L.xsc + d * c.Npad + p0);
+                const f32x4 xp = *reinterpret_cast<const f32x4*>(lds_f + c.L.xsc + d * c.Npad + p0);
+                const f32x2 xb = {xq[d], xq[d]};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { float df = xp[e] - xq[d]; r2[e] = (d == 0) ? df * df : fmaf(df, df, r2[e]); }
+                for (int e = 0; e < 2; ++e) {
+                    const f32x2 xa = {xp[2 * e], xp[2 * e + 1]};
+                    const f32x2 df = xa - xb;
+                    r2[e] = (d == 0) ? df * df : __builtin_elementwise_fma(df, df, r2[e]);
+                }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float kf, gg;
-                kfun<KERN>(r2[e], kf, gg);
+                kfun<KERN>(r2[e >> 1][e & 1], kf, gg);
                 out[4 * qq + e] = c.sf2 * kf;
             }
         }
@@ -354,33 +364,41 @@ __device__ __forceinline__ void contract_t(const Ctx<D, KERN>& c, const f32x16& 
     }
     if (ba != bb && 32 * ba + 32 <= c.N && 32 * bb + 32 <= c.N) {
         // interior off-diagonal block: no masks, no diagonal term; the block weight is applied once to the block's sums
-        float bl[D], bsf = 0.f;
+        // row pairs in packed fp32; even and odd rows keep separate partial sums
+        f32x2 bl[D], bsf = {0.f, 0.f};
 #pragma unroll
-        for (int d = 0; d < D; ++d) bl[d] = 0.f;
+        for (int d = 0; d < D; ++d) bl[d] = f32x2{0.f, 0.f};
+        const f32x2 naq = {-aq, -aq};
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float d2[D];
-                float r2 = 0.f;
+            for (int e = 0; e < 2; ++e) {
+                f32x2 d2[D];
+                f32x2 r2 = {0.f, 0.f};
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    const float df = xp[qq][d][e] - xq[d];
+                    const f32x2 xa = {xp[qq][d][2 * e], xp[qq][d][2 * e + 1]};
+                    const f32x2 xb = {xq[d], xq[d]};
+                    const f32x2 df = xa - xb;
                     d2[d] = df * df;
                     r2 = (d == 0) ? d2[d] : r2 + d2[d];
                 }
-                float kf, gg;
-                kfun<KERN>(r2, kf, gg);
-                const float Q = fmaf(-ap[qq][e], aq, kinv[4 * qq + e]);
-                bsf = fmaf(Q, kf, bsf);
-                const float wg = Q * gg;
+                float kf0, gg0, kf1, gg1;
+                kfun<KERN>(r2[0], kf0, gg0);
+                kfun<KERN>(r2[1], kf1, gg1);
+                const f32x2 kf = {kf0, kf1}, gg = {gg0, gg1};
+                const f32x2 apv = {ap[qq][2 * e], ap[qq][2 * e + 1]};
+                const f32x2 kv = {kinv[4 * qq + 2 * e], kinv[4 * qq + 2 * e + 1]};
+                const f32x2 Q = __builtin_elementwise_fma(apv, naq, kv);
+                bsf = __builtin_elementwise_fma(Q, kf, bsf);
+                const f32x2 wg = Q * gg;
 #pragma unroll
-                for (int d = 0; d < D; ++d) bl[d] = fmaf(wg, d2[d], bl[d]);
+                for (int d = 0; d < D; ++d) bl[d] = __builtin_elementwise_fma(wg, d2[d], bl[d]);
             }
         }
-        accsf = fmaf(wgt, bsf, accsf);
+        accsf = fmaf(wgt, bsf[0] + bsf[1], accsf);
 #pragma unroll
-        for (int d = 0; d < D; ++d) accl[d] = fmaf(wgt, bl[d], accl[d]);
+        for (int d = 0; d < D; ++d) accl[d] = fmaf(wgt, bl[d][0] + bl[d][1], accl[d]);
         return;
     }
 #pragma unroll
@@ -591,7 +609,7 @@ __device__ __forceinline__ void pt_group_kloop(const Ctx<D, KN>& c, const Panel<
             B0 = nB0;
         }
     }
-#elif defined(GPSAT_EXP_UNROLL2)  // experiment E12': two k-steps per trip, the operand sets swap roles (no copies)
+#elif (GPSAT_EXP_UNROLL2 & 1)  // experiment E12': two k-steps per trip, the operand sets swap roles (no copies)
     if (kmin < j0) {
         f32x16 A0 = ldg(c.ws, kmin * NB + j0, lane);
         f32x16 A1 = ldg(c.ws, p.has1 ? kmin * NB + p.j1 : c.zb, lane);
@@ -1141,7 +1159,7 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
                     A1 = ldg(c.ws, cn * NB + a1, lane);
                     B0 = nB0;
                 }
-#elif defined(GPSAT_EXP_UNROLL2)
+#elif (GPSAT_EXP_UNROLL2 & 2)
                 int cc = a1;
                 for (; cc + 1 < NB; cc += 2) {
                     const int cn = cc + 1;
