@@ -581,7 +581,11 @@ __device__ __forceinline__ void pt_group_kloop(const Ctx<D, KN>& c, const Panel<
     const bool u0 = e0 < p.nU, u1 = e1 < p.nU;
     const int c0 = v0 ? pt_item_col(p, e0) : 0, c1 = v1 ? pt_item_col(p, e1) : 0;
     const int ks0 = v0 ? (u0 ? 0 : c0) : j0, ks1 = v1 ? (u1 ? 0 : c1) : j0;
+#if GPSAT_EXP_ABL == 8           // ablation: no k-loops
+    const int kmin = j0;
+#else
     const int kmin = min(ks0, ks1);
+#endif
 #pragma unroll
     for (int n = 0; n < 4; ++n) W[n] = zero16();
 #ifdef GPSAT_EXP_INPLACE        // experiment E13': slower by 1.2 % (the refill has 2048 instead of 4096 MFMA cycles to arrive)
@@ -651,21 +655,24 @@ __device__ __forceinline__ void pt_group_kloop(const Ctx<D, KN>& c, const Panel<
         f32x16 A1 = ldg(c.ws, p.has1 ? kmin * NB + p.j1 : c.zb, lane);
         f32x16 B0 = ldg(c.ws, (kmin >= ks0) ? kmin * NB + c0 : c.zb, lane);
         f32x16 B1 = ldg(c.ws, (kmin >= ks1) ? kmin * NB + c1 : c.zb, lane);
-        for (int k = kmin; k < j0; ++k) {
-            f32x16 nA0 = A0, nA1 = A1, nB0 = B0, nB1 = B1;
-            if (k + 1 < j0) {
-                const int kn = k + 1;
-                nA0 = ldg(c.ws, kn * NB + j0, lane);
-                nA1 = ldg(c.ws, p.has1 ? kn * NB + p.j1 : c.zb, lane);
-                nB0 = ldg(c.ws, (kn >= ks0) ? kn * NB + c0 : c.zb, lane);
-                nB1 = ldg(c.ws, (kn >= ks1) ? kn * NB + c1 : c.zb, lane);
-            }
+        // the last step is peeled: inside the loop the next operands are loaded unconditionally (a conditional load made
+        // the compiler copy the current set into the next one first: 128 instead of 64 register copies per step)
+        for (int k = kmin; k + 1 < j0; ++k) {
+            const int kn = k + 1;
+            const f32x16 nA0 = ldg(c.ws, kn * NB + j0, lane);
+            const f32x16 nA1 = ldg(c.ws, p.has1 ? kn * NB + p.j1 : c.zb, lane);
+            const f32x16 nB0 = ldg(c.ws, (kn >= ks0) ? kn * NB + c0 : c.zb, lane);
+            const f32x16 nB1 = ldg(c.ws, (kn >= ks1) ? kn * NB + c1 : c.zb, lane);
             mma_blk(W[0], A0, B0);
             mma_blk(W[1], A0, B1);
             mma_blk(W[2], A1, B0);
             mma_blk(W[3], A1, B1);
             A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
         }
+        mma_blk(W[0], A0, B0);
+        mma_blk(W[1], A0, B1);
+        mma_blk(W[2], A1, B0);
+        mma_blk(W[3], A1, B1);
     }
 #endif
     // U-type: W = K - acc ; M-type: W = -acc
@@ -706,7 +713,7 @@ __device__ __forceinline__ void pt_group_row(const Ctx<D, KN>& c, const Panel<D>
             f32x16 X = zero16();
             mma_blk(X, Lop, src);
             stg(c.ws, jr * NB + col, lane, X);          // U-type: upper slot (jr,col); M-type: lower slot
-            if (!isu) {
+            if (!isu && GPSAT_EXP_ABL != 7) {
                 float ap = 0.f;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) ap = fmaf(X[q], lds_f[c.L.z + 32 * jr + rho(q, c.h)], ap);
@@ -747,11 +754,10 @@ __device__ __forceinline__ void chain_kloop(const Ctx<D, KN>& c, const Panel<D>&
     f32x16 A0 = ldg(c.ws, kb * NB + j0, lane);
     f32x16 A1 = ldg(c.ws, has1 ? kb * NB + j1 : c.zb, lane);
     for (int k = kb; k < ke; ++k) {
-        f32x16 nA0 = A0, nA1 = A1;
-        if (k + 1 < ke) {
-            nA0 = ldg(c.ws, (k + 1) * NB + j0, lane);
-            nA1 = ldg(c.ws, has1 ? (k + 1) * NB + j1 : c.zb, lane);
-        }
+        // the operands of the step after the last are a (harmless) reload of the last: no conditional load, no copy-first
+        const int kn = min(k + 1, ke - 1);
+        const f32x16 nA0 = ldg(c.ws, kn * NB + j0, lane);
+        const f32x16 nA1 = ldg(c.ws, has1 ? kn * NB + j1 : c.zb, lane);
         mma_blk(D00, A0, A0);
         mma_blk(D01, A0, A1);
         mma_blk(D11, A1, A1);
@@ -1134,7 +1140,7 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
             f32x16 B0 = ldg(c.ws, a0 * NB + b0, lane);
             f32x16 B1 = ldg(c.ws, use01 ? a0 * NB + b1 : c.zb, lane);
             f32x16 A1 = A0;
-            if (a0 + 1 < NB) {
+            if (a0 + 1 < NB && GPSAT_EXP_ABL != 8) {
                 f32x16 nA0 = ldg(c.ws, a1 * NB + a0, lane);
                 f32x16 nA1 = ldg(c.ws, a1 * NB + a1, lane);
                 f32x16 nB0 = ldg(c.ws, a1 * NB + b0, lane);
@@ -1190,21 +1196,22 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
                     if (hasb1) mma_blk(acc[3], A1, B1);
                 }
 #else
-                for (int cc = a1; cc < NB; ++cc) {
-                    nA0 = A0; nA1 = A1; nB0 = B0; nB1 = B1;
-                    if (cc + 1 < NB) {
-                        const int cn = cc + 1;
-                        nA0 = ldg(c.ws, cn * NB + a0, lane);
-                        nA1 = ldg(c.ws, cn * NB + a1, lane);
-                        nB0 = ldg(c.ws, cn * NB + b0, lane);
-                        nB1 = ldg(c.ws, hasb1 ? cn * NB + b1 : c.zb, lane);
-                    }
+                for (int cc = a1; cc + 1 < NB; ++cc) {          // last step peeled, as in pt_group_kloop
+                    const int cn = cc + 1;
+                    nA0 = ldg(c.ws, cn * NB + a0, lane);
+                    nA1 = ldg(c.ws, cn * NB + a1, lane);
+                    nB0 = ldg(c.ws, cn * NB + b0, lane);
+                    nB1 = ldg(c.ws, hasb1 ? cn * NB + b1 : c.zb, lane);
                     mma_blk(acc[0], A0, B0);
                     if (use01) mma_blk(acc[1], A0, B1);
                     mma_blk(acc[2], A1, B0);
                     if (hasb1) mma_blk(acc[3], A1, B1);
                     A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
                 }
+                mma_blk(acc[0], A0, B0);
+                if (use01) mma_blk(acc[1], A0, B1);
+                mma_blk(acc[2], A1, B0);
+                if (hasb1) mma_blk(acc[3], A1, B1);
 #endif
             } else {
                 mma_blk(acc[0], A0, B0);
