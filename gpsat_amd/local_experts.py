@@ -572,9 +572,11 @@ class BatchedLocalExpertOI:
     def run(self, store_path: Optional[str] = None, optimise: bool = True, predict: bool = True, min_obs: int = 3,
             table_suffix: str = "", max_tiles_per_call: Optional[int] = None, store_every: Optional[int] = None,
             check_config_compatible: bool = True, skip_valid_checks_on: Optional[List[str]] = None,
-            rank: Optional[int] = None, world_size: Optional[int] = None, gather: bool = True):
+            rank: Optional[int] = None, world_size: Optional[int] = None, gather: bool = True,
+            engine_chunk: Optional[int] = None):
         """See the module docstring.  ``store_every``: expert locations per flushed wave (default 4096;
-        ``max_tiles_per_call`` is the older name of the same knob).  ``rank`` / ``world_size``: tile-sharded run, one
+        ``max_tiles_per_call`` is the older name of the same knob).  ``engine_chunk``: tiles per engine call inside a wave
+        (default 2048): while the GPU works on one call the host packs the next (gather, scale, de-mean, centre, cast).  ``rank`` / ``world_size``: tile-sharded run, one
         process per GPU (default: taken from an initialised ``torch.distributed`` group, else 0 / 1); with
         ``gather=True`` rank 0 returns the global tables in expert order, the other ranks their own shard's.
         ``world_size > 1`` with ``rank=None`` and no process group runs all the LOGICAL shards one after the other on
@@ -593,6 +595,7 @@ class BatchedLocalExpertOI:
         D, H = len(cc), len(cc) + 2
         xl = self.expert_locs
         wave_n = int(store_every or max_tiles_per_call or 4096)
+        chunk_n = max(1, int(engine_chunk or 2048))
         # ---- expert_locs table + config bookkeeping (local_experts.py:873-903); rank 0 owns the shared files
         config_id = 1
         if store_path:
@@ -715,7 +718,7 @@ class BatchedLocalExpertOI:
         obs_all = self.df[self.obs_col].values.astype(np.float64)
         assert not np.isnan(coords_all).any(), "nans found in coords"
         assert not np.isnan(obs_all).any(), "nans found in obs"
-        self.timings.update(engine_s=0.0, tables_s=0.0, flush_s=0.0)
+        self.timings.update(pack_wait_s=0.0, engine_s=0.0, tables_s=0.0, flush_s=0.0)
 
         def tables_for(items, fixed, pred_cat):
             return self._tables(ex[items], locs[items], kind[items], n_obs[items], fixed, pred_cat,
@@ -723,34 +726,88 @@ class BatchedLocalExpertOI:
                                 [tmpl[p]["device"] for p in prof_id[items]], optimise, config_id, table_suffix)
 
         # ---------------- pass 2: waves of one shard ----------------
+        def pack_job(ids, pi):
+            """Host-side intake of one engine call (a1 of the reference in fp64): gather the tiles' rows, scale, de-mean."""
+            t_, p_ = tmpl[pi], pinfo[pi]
+            Ns = n_obs[ids]
+            rows = np.concatenate([idx[off[i]:off[i + 1]] for i in ids])
+            tile_of_row = np.repeat(np.arange(len(ids)), Ns)
+            X = coords_all[rows] / t_["coords_scale"]         # base_model.py:243
+            yv_ = obs_all[rows]
+            o_off = np.concatenate([[0], np.cumsum(Ns)]).astype(np.int64)
+            mean = (np.add.reduceat(yv_, o_off[:-1]) / Ns) if t_["local_mean"] else np.zeros(len(ids))
+            y = (yv_ - mean[tile_of_row]) / t_["obs_scale"]   # base_model.py:244-245
+            Ps = n_pred[ids] if predict else np.zeros(len(ids), dtype=np.int64)
+            p_off = np.concatenate([[0], np.cumsum(Ps)]).astype(np.int64)
+            Xs = np.concatenate([pcs[i] for i in ids]) if predict else np.zeros((0, D))
+            if p_["apply_scale"]:
+                Xs = Xs / t_["coords_scale"]
+            if self.dtype == "f32":
+                # what the engine does with fp64 host arrays for the fp32 kernels (per-tile centring, then the cast), done
+                # here so that it too overlaps the previous call
+                from .engine import centre_tiles
+                if len(X):
+                    X, Xs = centre_tiles(X, Xs, o_off, p_off)
+                X, y, Xs = (np.ascontiguousarray(v, dtype=np.float32) for v in (X, y, Xs))
+            return dict(o_off=o_off, X=X, y=y, p_off=p_off, Xs=Xs, mean=mean)
+
+        # ---------------- pass 2: waves of one shard ----------------
+        # A wave (the flush unit) is cut into engine calls of at most `engine_chunk` tiles; the next call's arrays are packed
+        # by a helper thread while the GPU works on the current one (ctypes releases the GIL during the call).  Per-tile
+        # results do not depend on how tiles are batched (tests/test_gpu_parity.py::test_ragged_batch_tile_indexing_is_bit_exact).
         def run_shard(mine, shard_store):
+            from concurrent.futures import ThreadPoolExecutor
             fixed_rows, pred_rows = [], []
-            for w0 in range(0, len(mine), wave_n):
-                items = mine[w0:w0 + wave_n]
-                fixed = np.full((len(items), H + 6), np.nan)        # theta, nll, status, n_eval, n_iter, seconds, obs mean
-                preds = [np.zeros((0, 3))] * len(items)
+            jobs = []                                                  # (wave index, profile, positions within the wave)
+            waves = [mine[w0:w0 + wave_n] for w0 in range(0, len(mine), wave_n)]
+            for wi, items in enumerate(waves):
                 for pi in tmpl:
                     loc_ids = np.nonzero((kind[items] == 2) & (prof_id[items] == pi))[0]
-                    if len(loc_ids) == 0:
-                        continue
-                    ids = items[loc_ids]
+                    for c0 in range(0, len(loc_ids), chunk_n):
+                        jobs.append((wi, pi, loc_ids[c0:c0 + chunk_n]))
+            last_job_of_wave = {wi: k for k, (wi, _, _) in enumerate(jobs)}
+            state = {}
+
+            def open_wave(wi):
+                items = waves[wi]
+                state[wi] = (np.full((len(items), H + 6), np.nan),       # theta, nll, status, n_eval, n_iter, seconds, obs mean
+                             [np.zeros((0, 3))] * len(items))
+
+            def close_wave(wi):
+                items = waves[wi]
+                fixed, preds = state.pop(wi)
+                tt = time.perf_counter()
+                pred_cat = np.concatenate(preds) if len(preds) else np.zeros((0, 3))
+                tables = tables_for(items, fixed, pred_cat)
+                self.timings["tables_s"] += time.perf_counter() - tt
+                tf = time.perf_counter()
+                shard_store.write_wave(tables)                        # commit: these experts are done
+                self.timings["flush_s"] += time.perf_counter() - tf
+                fixed_rows.append(fixed)
+                pred_rows.append(pred_cat)
+
+            with ThreadPoolExecutor(max_workers=1) as pool:
+                nxt = pool.submit(pack_job, waves[jobs[0][0]][jobs[0][2]], jobs[0][1]) if jobs else None
+                done_waves = 0
+                for k, (wi, pi, loc_ids) in enumerate(jobs):
+                    while done_waves < wi:                            # waves without a single model tile (stubs, errors only)
+                        if done_waves not in state:
+                            open_wave(done_waves)
+                        close_wave(done_waves)
+                        done_waves += 1
+                    if wi not in state:
+                        open_wave(wi)
+                    fixed, preds = state[wi]
+                    ids = waves[wi][loc_ids]
+                    te = time.perf_counter()
+                    pk = nxt.result()
+                    self.timings["pack_wait_s"] += time.perf_counter() - te
+                    if k + 1 < len(jobs):
+                        nxt = pool.submit(pack_job, waves[jobs[k + 1][0]][jobs[k + 1][2]], jobs[k + 1][1])
                     t_, p_ = tmpl[pi], pinfo[pi]
                     te = time.perf_counter()
-                    Ns = n_obs[ids]
-                    rows = np.concatenate([idx[off[i]:off[i + 1]] for i in ids])
-                    tile_of_row = np.repeat(np.arange(len(ids)), Ns)
-                    X = coords_all[rows] / t_["coords_scale"]         # base_model.py:243
-                    yv_ = obs_all[rows]
-                    o_off = np.concatenate([[0], np.cumsum(Ns)]).astype(np.int64)
-                    mean = (np.add.reduceat(yv_, o_off[:-1]) / Ns) if t_["local_mean"] else np.zeros(len(ids))
-                    y = (yv_ - mean[tile_of_row]) / t_["obs_scale"]   # base_model.py:244-245
-                    Ps = n_pred[ids] if predict else np.zeros(len(ids), dtype=np.int64)
-                    p_off = np.concatenate([[0], np.cumsum(Ps)]).astype(np.int64)
-                    Xs = np.concatenate([pcs[i] for i in ids]) if predict else np.zeros((0, D))
-                    if p_["apply_scale"]:
-                        Xs = Xs / t_["coords_scale"]
-                    r = self.engine.fit_predict_batch(D=D, obs_off=o_off, X=X, y=y, pred_off=p_off, Xs=Xs,
-                                                      theta0=theta0[ids], lo=lo[ids], hi=hi[ids],
+                    r = self.engine.fit_predict_batch(D=D, obs_off=pk["o_off"], X=pk["X"], y=pk["y"], pred_off=pk["p_off"],
+                                                      Xs=pk["Xs"], theta0=theta0[ids], lo=lo[ids], hi=hi[ids],
                                                       trainable=t_["trainable"], kernel=p_["kernel"],
                                                       optimiser=p_["optimiser"], max_iter=p_["max_iter"],
                                                       dtype=self.dtype, **p_["eng_kw"])
@@ -762,21 +819,21 @@ class BatchedLocalExpertOI:
                     fixed[loc_ids, H + 2] = r.n_eval
                     fixed[loc_ids, H + 3] = r.n_iter if getattr(r, "n_iter", None) is not None else np.nan
                     fixed[loc_ids, H + 4] = dt
-                    fixed[loc_ids, H + 5] = mean
+                    fixed[loc_ids, H + 5] = pk["mean"]
                     if predict:
                         pr = np.stack([np.asarray(r.f_mean, dtype=np.float64), np.asarray(r.f_var, dtype=np.float64),
                                        np.asarray(r.y_var, dtype=np.float64)], axis=1)
-                        for k, j in enumerate(loc_ids):
-                            preds[j] = pr[p_off[k]:p_off[k + 1]]
-                tt = time.perf_counter()
-                pred_cat = np.concatenate(preds) if len(preds) else np.zeros((0, 3))
-                tables = tables_for(items, fixed, pred_cat)
-                self.timings["tables_s"] += time.perf_counter() - tt
-                tf = time.perf_counter()
-                shard_store.write_wave(tables)                        # commit: these experts are done
-                self.timings["flush_s"] += time.perf_counter() - tf
-                fixed_rows.append(fixed)
-                pred_rows.append(pred_cat)
+                        p_off = pk["p_off"]
+                        for kk, j in enumerate(loc_ids):
+                            preds[j] = pr[p_off[kk]:p_off[kk + 1]]
+                    if last_job_of_wave[wi] == k:
+                        close_wave(wi)
+                        done_waves = wi + 1
+                while done_waves < len(waves):
+                    if done_waves not in state:
+                        open_wave(done_waves)
+                    close_wave(done_waves)
+                    done_waves += 1
             fixed_all = np.concatenate(fixed_rows) if fixed_rows else np.zeros((0, H + 6))
             preds_all = np.concatenate(pred_rows) if pred_rows else np.zeros((0, 3))
             cnt = np.where(kind[mine] == 2, n_pred[mine] if predict else 0, 0).astype(np.int64)
