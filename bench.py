@@ -131,7 +131,7 @@ def build_workload(a, rank, world, workers):
                  Xs=np.concatenate([r[2] for r in res]).astype(np.float32), theta0=np.ones((T, D + 2)), lo=lo, hi=hi,
                  data="synthetic")
     elif a.workload == "configs2":
-        T = a.tiles if a.tiles != 4096 else 1024
+        T = a.tiles                     # BASELINE configs[2]: 4096 ragged tiles (a 1024-tile launch is as long as its largest tile)
         kid = 2
         sizes = [128, 256, 384, 512, 768, 1024, 1536, 2048]
         Ns = np.random.default_rng(rank).choice(sizes, T)
