@@ -351,61 +351,77 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
         }
         __syncthreads();
         if (sh->fail) break;
-        // ---- (C) columns right of the panel, two per wave and step: 4 x 2 accumulators, operands of step k+1 in flight
-        for (int i0 = j0 + nr + 2 * w; i0 < NB; i0 += 2 * NW) {
-            const int ib0 = i0, ib1 = (i0 + 1 < NB) ? i0 + 1 : -1;
-            f64x4 acc[PR][2];
+        // ---- (C) columns right of the panel, PCW per wave and step: 4 x PCW accumulators, operands of step k+1 in flight.
+        // The factor of an N = 2000 tile lives in HBM / Infinity Cache and this loop runs at what the fabric delivers (5.7 TB/s
+        // measured with 4 x 2 accumulators = 0.75 block loads per product); 4 x 3 needs 7 loads per 12 products.
+        constexpr int PCW = 3;
+        for (int i0 = j0 + nr + PCW * w; i0 < NB; i0 += PCW * NW) {
+            int ib[PCW];
 #pragma unroll
-            for (int r = 0; r < PR; ++r) { acc[r][0] = zero4(); acc[r][1] = zero4(); }
+            for (int cc = 0; cc < PCW; ++cc) ib[cc] = (i0 + cc < NB) ? i0 + cc : -1;
+            f64x4 acc[PR][PCW];
+#pragma unroll
+            for (int r = 0; r < PR; ++r)
+#pragma unroll
+                for (int cc = 0; cc < PCW; ++cc) acc[r][cc] = zero4();
             if (j0 > 0) {
-                f64x4 A[PR], B0, B1;
+                f64x4 A[PR], B[PCW];
 #pragma unroll
                 for (int r = 0; r < PR; ++r) A[r] = ldg(c.ws, (r < nr) ? j0 + r : c.zb, lane);
-                B0 = ldg(c.ws, ib0, lane);
-                B1 = ldg(c.ws, ib1 >= 0 ? ib1 : c.zb, lane);
-                for (int k = 0; k < j0; ++k) {
-                    f64x4 nA[PR], nB0 = B0, nB1 = B1;
 #pragma unroll
-                    for (int r = 0; r < PR; ++r) nA[r] = A[r];
-                    if (k + 1 < j0) {
+                for (int cc = 0; cc < PCW; ++cc) B[cc] = ldg(c.ws, ib[cc] >= 0 ? ib[cc] : c.zb, lane);
+                // last step peeled: the loads of the next operands are unconditional (a conditional load makes the compiler
+                // copy the whole operand set first)
+                for (int k = 0; k + 1 < j0; ++k) {
+                    f64x4 nA[PR], nB[PCW];
 #pragma unroll
-                        for (int r = 0; r < PR; ++r) nA[r] = ldg(c.ws, (r < nr) ? (k + 1) * NB + j0 + r : c.zb, lane);
-                        nB0 = ldg(c.ws, (k + 1) * NB + ib0, lane);
-                        nB1 = ldg(c.ws, ib1 >= 0 ? (k + 1) * NB + ib1 : c.zb, lane);
-                    }
+                    for (int r = 0; r < PR; ++r) nA[r] = ldg(c.ws, (r < nr) ? (k + 1) * NB + j0 + r : c.zb, lane);
 #pragma unroll
-                    for (int r = 0; r < PR; ++r) { mma_blk(acc[r][0], A[r], B0); mma_blk(acc[r][1], A[r], B1); }
+                    for (int cc = 0; cc < PCW; ++cc) nB[cc] = ldg(c.ws, ib[cc] >= 0 ? (k + 1) * NB + ib[cc] : c.zb, lane);
+#pragma unroll
+                    for (int r = 0; r < PR; ++r)
+#pragma unroll
+                        for (int cc = 0; cc < PCW; ++cc) mma_blk(acc[r][cc], A[r], B[cc]);
 #pragma unroll
                     for (int r = 0; r < PR; ++r) A[r] = nA[r];
-                    B0 = nB0; B1 = nB1;
+#pragma unroll
+                    for (int cc = 0; cc < PCW; ++cc) B[cc] = nB[cc];
                 }
+#pragma unroll
+                for (int r = 0; r < PR; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < PCW; ++cc) mma_blk(acc[r][cc], A[r], B[cc]);
             }
             // right-hand sides, then the in-panel triangular solve: X_r = L_r^-1 (W_r - sum_{r''<r} U_r''r^T X_r'')
 #pragma unroll
             for (int r = 0; r < PR; ++r) {
                 if (r < nr) {
-                    acc[r][0] = kblock<D, KN>(c, j0 + r, ib0) - acc[r][0];
-                    if (ib1 >= 0) acc[r][1] = kblock<D, KN>(c, j0 + r, ib1) - acc[r][1];
+#pragma unroll
+                    for (int cc = 0; cc < PCW; ++cc)
+                        if (ib[cc] >= 0) acc[r][cc] = kblock<D, KN>(c, j0 + r, ib[cc]) - acc[r][cc];
                 }
             }
 #pragma unroll
             for (int r = 0; r < PR; ++r) {
                 if (r < nr) {
                     const f64x4 Lop = ldl(c.L.Pn + pidx(r, r) * BLK, lane);
-                    f64x4 X0 = zero4(), X1 = zero4();
-                    mma_blk(X0, Lop, acc[r][0]);
-                    mma_blk(X1, Lop, acc[r][1]);
-                    stg(c.ws, (j0 + r) * NB + ib0, lane, X0);
-                    if (ib1 >= 0) stg(c.ws, (j0 + r) * NB + ib1, lane, X1);
+                    f64x4 X[PCW];
+#pragma unroll
+                    for (int cc = 0; cc < PCW; ++cc) {
+                        X[cc] = zero4();
+                        mma_blk(X[cc], Lop, acc[r][cc]);
+                        if (ib[cc] >= 0) stg(c.ws, (j0 + r) * NB + ib[cc], lane, X[cc]);
+                    }
 #pragma unroll
                     for (int r2 = r + 1; r2 < PR; ++r2) {
                         if (r2 < nr) {
                             const f64x4 U = ldl(c.L.Pn + pidx(r, r2) * BLK, lane);
-                            f64x4 T0 = zero4(), T1 = zero4();
-                            mma_blk(T0, U, X0);
-                            mma_blk(T1, U, X1);
-                            acc[r2][0] -= T0;
-                            acc[r2][1] -= T1;
+#pragma unroll
+                            for (int cc = 0; cc < PCW; ++cc) {
+                                f64x4 T = zero4();
+                                mma_blk(T, U, X[cc]);
+                                acc[r2][cc] -= T;
+                            }
                         }
                     }
                 }
