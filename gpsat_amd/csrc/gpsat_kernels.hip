@@ -1344,17 +1344,16 @@ __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const float* __restr
                 f32x16 A = ldg(c.ws, j, lane);                 // U_0,j
                 f32x16 B0 = ldg(c.ws, v0, lane);
                 f32x16 B1 = ldg(c.ws, v0 + NB, lane);
-                for (int k = 0; k < j; ++k) {
-                    f32x16 nA = A, nB0 = B0, nB1 = B1;
-                    if (k + 1 < j) {
-                        nA = ldg(c.ws, (k + 1) * NB + j, lane);
-                        nB0 = ldg(c.ws, v0 + k + 1, lane);
-                        nB1 = ldg(c.ws, v0 + NB + k + 1, lane);
-                    }
+                for (int k = 0; k + 1 < j; ++k) {              // last step peeled (see pt_group_kloop)
+                    const f32x16 nA = ldg(c.ws, (k + 1) * NB + j, lane);
+                    const f32x16 nB0 = ldg(c.ws, v0 + k + 1, lane);
+                    const f32x16 nB1 = ldg(c.ws, v0 + NB + k + 1, lane);
                     mma_blk(acc0, A, B0);
                     mma_blk(acc1, A, B1);
                     A = nA; B0 = nB0; B1 = nB1;
                 }
+                mma_blk(acc0, A, B0);
+                mma_blk(acc1, A, B1);
             }
             const f32x16 Lop = ldg(c.ws, c.dT0 + j, lane);
             f32x16 Wa = ksblock<D, KN>(c, j, xa, va) - acc0;
@@ -1394,15 +1393,13 @@ __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const float* __restr
                 if ((idx & (NW - 1)) != c.w) continue;
                 f32x16 Cb = zero16();
                 f32x16 A = ldg(c.ws, c.cv0 + p * NB, lane), B = ldg(c.ws, c.cv0 + q * NB, lane);
-                for (int k = 0; k < NB; ++k) {
-                    f32x16 nA = A, nB = B;
-                    if (k + 1 < NB) {
-                        nA = ldg(c.ws, c.cv0 + p * NB + k + 1, lane);
-                        nB = ldg(c.ws, c.cv0 + q * NB + k + 1, lane);
-                    }
+                for (int k = 0; k + 1 < NB; ++k) {
+                    const f32x16 nA = ldg(c.ws, c.cv0 + p * NB + k + 1, lane);
+                    const f32x16 nB = ldg(c.ws, c.cv0 + q * NB + k + 1, lane);
                     mma_blk(Cb, A, B);
                     A = nA; B = nB;
                 }
+                mma_blk(Cb, A, B);
                 const int qj = 32 * q + c.g;
                 const bool vj = qj < c.P;
                 float xq[D];

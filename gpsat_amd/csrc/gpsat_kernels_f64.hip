@@ -454,21 +454,21 @@ __device__ __forceinline__ void phase_trtri(Ctx<D, KN>& c) {
                 for (int r = 0; r < PR; ++r) A[r] = ldg(c.ws, (r < nr) ? jc0 * NB + i0 + r : c.zb, lane);
                 B0 = ldg(c.ws, jc0 * NB + jc0, lane);
                 B1 = ldg(c.ws, c.zb, lane);                         // M_k,jc1 is zero for k = jc0 < jc1
-                for (int k = jc0; k < i0; ++k) {
-                    f64x4 nA[PR], nB0 = B0, nB1 = B1;
+                for (int k = jc0; k + 1 < i0; ++k) {          // last step peeled: unconditional loads, no copy-first
+                    f64x4 nA[PR], nB0, nB1;
 #pragma unroll
-                    for (int r = 0; r < PR; ++r) nA[r] = A[r];
-                    if (k + 1 < i0) {
-#pragma unroll
-                        for (int r = 0; r < PR; ++r) nA[r] = ldg(c.ws, (r < nr) ? (k + 1) * NB + i0 + r : c.zb, lane);
-                        nB0 = ldg(c.ws, (k + 1) * NB + jc0, lane);
-                        nB1 = ldg(c.ws, (k + 1) * NB + jc1, lane);
-                    }
+                    for (int r = 0; r < PR; ++r) nA[r] = ldg(c.ws, (r < nr) ? (k + 1) * NB + i0 + r : c.zb, lane);
+                    nB0 = ldg(c.ws, (k + 1) * NB + jc0, lane);
+                    nB1 = ldg(c.ws, (k + 1) * NB + jc1, lane);
 #pragma unroll
                     for (int r = 0; r < PR; ++r) { mma_blk(acc[r][0], A[r], B0); mma_blk(acc[r][1], A[r], B1); }
 #pragma unroll
                     for (int r = 0; r < PR; ++r) A[r] = nA[r];
                     B0 = nB0; B1 = nB1;
+                }
+                if (jc0 < i0) {
+#pragma unroll
+                    for (int r = 0; r < PR; ++r) { mma_blk(acc[r][0], A[r], B0); mma_blk(acc[r][1], A[r], B1); }
                 }
             }
             double ap0 = 0.0, ap1 = 0.0;
@@ -562,22 +562,22 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
                 for (int r = 0; r < PR; ++r) A[r] = ldg(c.ws, (r < na && a0 >= a0 + r) ? a0 * NB + a0 + r : c.zb, lane);
                 B0 = ldg(c.ws, (a0 >= b0) ? a0 * NB + b0 : c.zb, lane);
                 B1 = ldg(c.ws, (hb1 && a0 >= b0 + 1) ? a0 * NB + b0 + 1 : c.zb, lane);
-                for (int cc = a0; cc < NB; ++cc) {
-                    f64x4 nA[PR], nB0 = B0, nB1 = B1;
+                for (int cc = a0; cc + 1 < NB; ++cc) {          // last step peeled: unconditional loads, no copy-first
+                    f64x4 nA[PR], nB0, nB1;
+                    const int cn = cc + 1;
 #pragma unroll
-                    for (int r = 0; r < PR; ++r) nA[r] = A[r];
-                    if (cc + 1 < NB) {
-                        const int cn = cc + 1;
-#pragma unroll
-                        for (int r = 0; r < PR; ++r) nA[r] = ldg(c.ws, (r < na && cn >= a0 + r) ? cn * NB + a0 + r : c.zb, lane);
-                        nB0 = ldg(c.ws, (cn >= b0) ? cn * NB + b0 : c.zb, lane);
-                        nB1 = ldg(c.ws, (hb1 && cn >= b0 + 1) ? cn * NB + b0 + 1 : c.zb, lane);
-                    }
+                    for (int r = 0; r < PR; ++r) nA[r] = ldg(c.ws, (r < na && cn >= a0 + r) ? cn * NB + a0 + r : c.zb, lane);
+                    nB0 = ldg(c.ws, (cn >= b0) ? cn * NB + b0 : c.zb, lane);
+                    nB1 = ldg(c.ws, (hb1 && cn >= b0 + 1) ? cn * NB + b0 + 1 : c.zb, lane);
 #pragma unroll
                     for (int r = 0; r < PR; ++r) { mma_blk(acc[r][0], A[r], B0); mma_blk(acc[r][1], A[r], B1); }
 #pragma unroll
                     for (int r = 0; r < PR; ++r) A[r] = nA[r];
                     B0 = nB0; B1 = nB1;
+                }
+                if (a0 < NB) {
+#pragma unroll
+                    for (int r = 0; r < PR; ++r) { mma_blk(acc[r][0], A[r], B0); mma_blk(acc[r][1], A[r], B1); }
                 }
             }
 #pragma unroll
@@ -689,21 +689,21 @@ __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const double* __rest
                 for (int r = 0; r < PR; ++r) A[r] = ldg(c.ws, (r < nr) ? j0 + r : c.zb, lane);
                 B0 = ldg(c.ws, v0, lane);
                 B1 = ldg(c.ws, v0 + NB, lane);
-                for (int k = 0; k < j0; ++k) {
-                    f64x4 nA[PR], nB0 = B0, nB1 = B1;
+                for (int k = 0; k + 1 < j0; ++k) {          // last step peeled: unconditional loads, no copy-first
+                    f64x4 nA[PR], nB0, nB1;
 #pragma unroll
-                    for (int r = 0; r < PR; ++r) nA[r] = A[r];
-                    if (k + 1 < j0) {
-#pragma unroll
-                        for (int r = 0; r < PR; ++r) nA[r] = ldg(c.ws, (r < nr) ? (k + 1) * NB + j0 + r : c.zb, lane);
-                        nB0 = ldg(c.ws, v0 + k + 1, lane);
-                        nB1 = ldg(c.ws, v0 + NB + k + 1, lane);
-                    }
+                    for (int r = 0; r < PR; ++r) nA[r] = ldg(c.ws, (r < nr) ? (k + 1) * NB + j0 + r : c.zb, lane);
+                    nB0 = ldg(c.ws, v0 + k + 1, lane);
+                    nB1 = ldg(c.ws, v0 + NB + k + 1, lane);
 #pragma unroll
                     for (int r = 0; r < PR; ++r) { mma_blk(acc[r][0], A[r], B0); mma_blk(acc[r][1], A[r], B1); }
 #pragma unroll
                     for (int r = 0; r < PR; ++r) A[r] = nA[r];
                     B0 = nB0; B1 = nB1;
+                }
+                if (0 < j0) {
+#pragma unroll
+                    for (int r = 0; r < PR; ++r) { mma_blk(acc[r][0], A[r], B0); mma_blk(acc[r][1], A[r], B1); }
                 }
             }
 #pragma unroll
