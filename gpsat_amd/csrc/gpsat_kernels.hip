@@ -773,8 +773,9 @@ __device__ __forceinline__ void chain_kloop(const Ctx<D, KN>& c, const Panel<D>&
 
 // The diagonal chain of panel p (one wave): D00/D01/D11 accumulation over k < j0, the two 32x32
 // factorisations, U_j0j1, the forward solve z and M_j1,j0.  Publishes the factors in LDS copy `par`.
-// kwait: rows >= kwait of the panel columns are produced concurrently by another wave in this slot;
-// the chain polls sh->g0done (>= slot) before touching them.
+// `slot` is the panel's index.  kwait: rows >= kwait of the panel columns (= the rows of the previous panel) arrive
+// last: parked as a finished k-loop by the column wave (`held`: the chain completes them itself) or, in the tail, written
+// by it (the chain then waits for sh->g0done >= slot).  Returns false when the evaluation has failed (waits unwound).
 template <int D, int KN>
 __device__ __forceinline__ bool pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const Panel<D>& q, const bool want_m, int par,
                                          int kwait, int slot, bool held, int lt_users) {
@@ -811,7 +812,7 @@ __device__ __forceinline__ bool pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const
         PROF_END(c, 10);
         TRACE(c, 4, slot);
         // Rows j0-2, j0-1 of this panel's two columns = group 0 of the previous panel q (both items U-type), whose k-loop the column
-        // wave parked in LDS (L.Wh) during the previous slot.  Finish them here (6 block products), store them for
+        // wave has parked in LDS (L.Wh).  Finish them here (6 block products), store them for
         // everybody else, and use them straight from registers as the last two k-steps of D00 / D01 / D11.
         const int qpar = par ^ 1;
         const f32x16 L0 = ldl(c.L.LT + (2 * qpar + 0) * BLK, lane);
@@ -1479,7 +1480,7 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
     c.L.alpha = off; off += NPmax;
     c.L.LT = off; off += 4 * BLK;
     c.L.U01 = off; off += 2 * BLK;
-    c.L.Wh = off; off += 4 * BLK;          // column wave: finished k-loop of the next group 0, parked across the barrier
+    c.L.Wh = off; off += 4 * BLK;          // column wave: finished k-loop of the next group 0, parked for the chain wave
     c.L.Ad = off; off += 32 * 33 + 3;       // 1059 -> keep the next offsets 16-B aligned
     off = (off + 3) & ~3;
     c.L.tmp = off; off += 32;
