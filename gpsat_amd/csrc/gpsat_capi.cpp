@@ -62,7 +62,7 @@ struct gpsat_handle {
     // device buffers (grown lazily, owned by the handle)
     DevBuf meta_i64, meta_f64, meta_misc, out_f64, out_i32, bulk_in, bulk_out, ws, prof, ring, state;
     DevBuf sel_pts, sel_refs, sel_cnt, sel_idx, sel_box;
-    unsigned long long prof_host[64 + 8 * 1024] = {0};     // counters + event trace (diagnostic build)
+    unsigned long long prof_host[64 + 8 * 1024 + 2048] = {0};     // counters + event trace + per-workgroup start / end (diagnostic build)
 };
 
 extern "C" {
@@ -517,6 +517,12 @@ int gpsat_glue_batch(gpsat_handle* h, int64_t R, int32_t G, int32_t ndim, int32_
 int gpsat_debug_profile(gpsat_handle* h, unsigned long long* out64) {
     if (!h || !out64) return GPSAT_EINVAL;
     std::memcpy(out64, h->prof_host, 64 * sizeof(unsigned long long));
+    return GPSAT_OK;
+}
+// per-workgroup first-tile start and kernel-exit times in 100 MHz ticks: [1024] starts then [1024] ends
+int gpsat_debug_spans(gpsat_handle* h, unsigned long long* out2048) {
+    if (!h || !out2048) return GPSAT_EINVAL;
+    std::memcpy(out2048, h->prof_host + 64 + 8 * 1024, 2048 * sizeof(unsigned long long));
     return GPSAT_OK;
 }
 // event trace of the first evaluation of workgroup 0: [8 waves][1024] entries (cycle << 16 | arg << 8 | code), 0 = unused

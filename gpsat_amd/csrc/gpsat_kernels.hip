@@ -1660,6 +1660,10 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
     }
 #ifdef GPSAT_PROFILE
     __syncthreads();
+    if (A.prof && c.tid == 0 && blockIdx.x < 1024) {       // when did this workgroup start and run out of work (100 MHz ticks)
+        A.prof[64 + 8 * 1024 + blockIdx.x] = prof_r0;
+        A.prof[64 + 8 * 1024 + 1024 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    }
     if (blockIdx.x == 0 && c.tid == 0) {       // whole-kernel span of workgroup 0 in both clocks: s_memtime ticks per 100 MHz tick
         sh->prof[14] = __builtin_amdgcn_s_memtime() - prof_k0;
         sh->prof[15] = __builtin_amdgcn_s_memrealtime() - prof_r0;
