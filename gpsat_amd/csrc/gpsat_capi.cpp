@@ -265,24 +265,25 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
 
     // ---- time slicing of the optimisation (fp32): with few tiles per resident workgroup, whole tiles as the scheduling unit
     // leave the GPU half empty while the last ones finish (4096 tiles on 512 workgroups: 8 % of the launch).  Tiles of
-    // similar cost are therefore served in slices of ~4 evaluations of a 512-point tile; a batch whose largest tile
+    // similar cost are therefore served in slices of ~4 evaluations of a 512-point tile (both precisions); a batch whose largest tile
     // dominates keeps the largest-first run-to-completion order (its critical path must not wait in a queue).
     int seg_cost = 0;
-    if (!f64 && b->optimiser != GPSAT_OPT_NONE && b->max_iter > 0) {
+    if (b->optimiser != GPSAT_OPT_NONE && b->max_iter > 0) {
         double sum_cost = 0.0, max_cost = 0.0;
         for (int t = 0; t < T; ++t) {
-            const double nb = (double)((b->obs_off[t + 1] - b->obs_off[t] + 31) / 32);
+            const double nb = (double)((b->obs_off[t + 1] - b->obs_off[t] + bs - 1) / bs);
             sum_cost += nb * nb * nb;
             max_cost = std::max(max_cost, nb * nb * nb);
         }
         const double tiles_per_wg = (double)T / grid;
-        if (T > grid && max_cost * 4.0 * grid <= sum_cost && tiles_per_wg <= 64.0) seg_cost = 4 * 16 * 16 * 16;
+        if (T > grid && max_cost * 4.0 * grid <= sum_cost && tiles_per_wg <= 64.0) seg_cost = 4 * (512 / bs) * (512 / bs) * (512 / bs);
         // developer / tests: slice length in NB^3 units (0 = off, 1 = every evaluation), whatever the batch looks like
         if (const char* e = std::getenv("GPSAT_DEBUG_SEG")) seg_cost = std::max(0, std::atoi(e));
     }
     unsigned long long* d_ring = nullptr; int* d_ring_ctl = nullptr; unsigned* d_state = nullptr;
     int ring_mask = 0;
-    const int state_words = w8 ? gpsat::state_words_w8() : gpsat::state_words();
+    const int state_words = f64 ? (d4 ? gpsat::state_words_f64_w4() : gpsat::state_words_f64())
+                                : (w8 ? gpsat::state_words_w8() : gpsat::state_words());
     if (seg_cost > 0) {
         size_t cap = 1; while (cap < (size_t)T + (size_t)grid + 1) cap <<= 1;
         ring_mask = (int)(cap - 1);

@@ -37,7 +37,7 @@ struct KernelArgs {
     const long long* cov_off;     // [T+1] element offsets into f_cov, or nullptr
     float* f_cov;                 // per tile P x P posterior covariance, or nullptr
     int PCmax;                    // max prediction chunks per tile (only used with f_cov)
-    // time slicing of the optimisation (fp32 kernels; seg_cost = 0: every tile runs to completion from `queue`):
+    // time slicing of the optimisation (seg_cost = 0: every tile runs to completion from `queue`):
     // tiles are served from a ring; after ~seg_cost / NB^3 evaluations an unfinished tile's optimiser state is saved and the
     // tile goes to the back of the ring, so that all tiles of a homogeneous batch finish together instead of leaving a tail
     unsigned long long* ring;     // [ring_mask + 1] entries (sequence + 1) << 32 | resumed << 31 | tile; first T preset
@@ -50,10 +50,12 @@ size_t shared_bytes(int D, int NBmax);
 // fp64 kernels (gpsat_kernels_f64.hip): X, y, Xs, f_* and ws of KernelArgs point at doubles, ws_stride counts doubles
 size_t shared_bytes_f64(int D, int NBmax);
 size_t workspace_doubles_per_wg_f64(int NBmax, int PCcov);
+int state_words_f64();
 hipError_t launch_tiles_f64(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream);
 // 4-wave build (gpsat_kernels_f64.hip -DGPSAT_F64_W4): two workgroups per CU for tiles whose LDS fits twice
 size_t shared_bytes_f64_w4(int D, int NBmax);
 size_t workspace_doubles_per_wg_f64_w4(int NBmax, int PCcov);
+int state_words_f64_w4();
 hipError_t launch_tiles_f64_w4(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream);
 size_t workspace_floats_per_wg(int NBmax, int PCcov);     // PCcov: prediction chunks kept for f_cov (0 = none)
 hipError_t launch_tiles(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream);

@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "gpsat_kernels.h"
+#include "gpsat_ring.h"
 
 // Diagnostic build only (-DGPSAT_PROFILE, scripts/phase_profile.py): per-wave cycle counters per code
 // segment, accumulated in LDS and flushed to KernelArgs::prof.  No stamp executes in the product build.
@@ -1433,34 +1434,6 @@ __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const float* __restr
 // ---------------------------------------------------------------------------------------------
 // the persistent kernel
 // ---------------------------------------------------------------------------------------------
-// ---------------------------------------------------------------------------------------------
-// time slicing (KernelArgs::seg_cost > 0): the tiles circulate through a ring in device memory.  An entry is
-// (sequence + 1) << 32 | resumed << 31 | tile; slot s lives at s & ring_mask.  The ring is larger than the number of tiles
-// plus the number of workgroups, so a slot is never rewritten before the workgroup that claimed it has read it.
-// One thread per workgroup calls these.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int ring_pop(const KernelArgs& A) {
-    const unsigned s = (unsigned)__hip_atomic_fetch_add(&A.ring_ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long* e = A.ring + (s & (unsigned)A.ring_mask);
-    for (int spins = 0;; ++spins) {
-        // relaxed polling: an agent-scope acquire invalidates the XCD's L2 each time, which every other workgroup pays for;
-        // the one acquire a resumed tile needs is the fence before its state is read (gp_tile_kernel)
-        const unsigned long long v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)(v >> 32) == s + 1u) return (int)(unsigned)v;
-        // nothing there yet: either a tile will be pushed back, or every tile is finished
-        if (__hip_atomic_load(&A.ring_ctl[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) return -1;
-        // never reached by design (minutes of polling): a lost entry must not hang the GPU; the host sees unfinished tiles
-        if (spins > (1 << 25)) return -1;
-        __builtin_amdgcn_s_sleep(64);
-    }
-}
-
-__device__ __forceinline__ void ring_push(const KernelArgs& A, int tile) {
-    const unsigned s = (unsigned)__hip_atomic_fetch_add(&A.ring_ctl[16], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long v = ((unsigned long long)(s + 1u) << 32) | 0x80000000ull | (unsigned)tile;
-    __hip_atomic_store(A.ring + (s & (unsigned)A.ring_mask), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 template <int D, int KN>
 __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelArgs A) {
     constexpr int H = D + 2;

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "gpsat_kernels.h"
+#include "gpsat_ring.h"
 
 namespace gpsat {
 // Two builds are linked (as for the fp32 kernels): the default, 8 waves per workgroup and one workgroup per CU, and
@@ -827,13 +828,22 @@ __global__ void __launch_bounds__(NT, F64_MIN_WG) gp_tile_kernel_f64(const Kerne
     o.optimiser = A.optimiser; o.max_iter = A.max_iter; o.max_ls = A.max_ls; o.want_grad_out = A.grad != nullptr;
     o.ftol = A.ftol; o.gtol = A.gtol; o.adam_lr = A.adam_lr; o.noise_rel = A.noise_rel;
 
+    const bool sliced = A.seg_cost > 0;          // time-sliced tile queue, as in the fp32 kernels (gpsat_kernels.hip)
     for (;;) {
         __syncthreads();
-        if (c.tid == 0) sh->tile = atomicAdd(A.queue, 1);
+        if (c.tid == 0) {
+            if (sliced) {
+                sh->tile = ring_pop(A);
+            } else {
+                const int slot = atomicAdd(A.queue, 1);
+                sh->tile = slot < A.T ? A.order[slot] : -1;
+            }
+        }
         __syncthreads();
-        const int slot = sh->tile;
-        if (slot >= A.T) break;
-        const int t = A.order[slot];
+        const int entry = sh->tile;
+        if (entry == -1) break;
+        const int t = entry & 0x7fffffff;
+        const bool resumed = entry < 0;
         const long long o0 = A.obs_off[t], o1 = A.obs_off[t + 1];
         const long long p0 = A.pred_off[t], p1 = A.pred_off[t + 1];
         c.N = (int)(o1 - o0);
@@ -874,6 +884,7 @@ __global__ void __launch_bounds__(NT, F64_MIN_WG) gp_tile_kernel_f64(const Kerne
                     f_cov[A.cov_off[t] + e] = sf2 * kf;
                 }
             }
+            if (sliced && c.tid == 0) __hip_atomic_fetch_add(&A.ring_ctl[32], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             continue;
         }
         for (int idx = c.tid; idx < c.Npad; idx += NT) {
@@ -881,7 +892,12 @@ __global__ void __launch_bounds__(NT, F64_MIN_WG) gp_tile_kernel_f64(const Kerne
             lds_d[c.L.z + idx] = 0.0;
             lds_d[c.L.alpha + idx] = 0.0;
         }
-        if (c.tid == 0) {
+        if (resumed) {
+            const unsigned* src = A.state + (size_t)t * A.state_words;
+            unsigned* dst = reinterpret_cast<unsigned*>(sh);
+            for (int i = c.tid; i < A.state_words; i += NT)
+                dst[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (c.tid == 0) {
             sh->n_eval = 0; sh->n_eval_opt = 0; sh->status = 5; sh->iter = 0; sh->hist_n = 0; sh->hist_pos = 0;
             sh->last_dec = 1e300;
             sh->fail = 0;
@@ -901,11 +917,24 @@ __global__ void __launch_bounds__(NT, F64_MIN_WG) gp_tile_kernel_f64(const Kerne
             sh->want_grad = optim ? 1 : o.want_grad_out;
         }
         __syncthreads();
-        for (;;) {
+        const int seg_evals = sliced ? max(1, A.seg_cost / (NB * NB * NB)) : 0x7fffffff;
+        bool suspended = false;
+        for (int nseg = 1;; ++nseg) {
             evaluate<D, KN>(c, sh->want_grad != 0, X + (size_t)o0 * D);
             if (c.tid == 0) opt_advance(sh, H, o);
             __syncthreads();
             if (sh->phase == PH_EXIT) break;
+            if (nseg >= seg_evals && sh->phase != PH_FINAL) { suspended = true; break; }
+        }
+        if (suspended) {
+            unsigned* dst = A.state + (size_t)t * A.state_words;
+            const unsigned* src = reinterpret_cast<const unsigned*>(sh);
+            for (int i = c.tid; i < A.state_words; i += NT)
+                __hip_atomic_store(&dst[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            if (c.tid == 0) ring_push(A, t);
+            continue;
         }
         if (c.tid == 0) {
             int st = sh->status;
@@ -931,6 +960,7 @@ __global__ void __launch_bounds__(NT, F64_MIN_WG) gp_tile_kernel_f64(const Kerne
                     for (long long qq = A.cov_off[t] + c.tid; qq < A.cov_off[t + 1]; qq += NT) f_cov[qq] = __builtin_nan("");
             }
         }
+        if (sliced && c.tid == 0) __hip_atomic_fetch_add(&A.ring_ctl[32], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -961,6 +991,8 @@ size_t F64FN(shared_bytes_f64)(int D, int NBmax) {
     const size_t dbl = (sizeof(F64NS::Shared) + 15) / 16 * 2 + D * NP + 3 * NP + F64NS::BLK + 16 * 17 + 16 + 10 * F64NS::BLK + 4 * F64NS::BS + 2;
     return (dbl * sizeof(double) + 15) & ~size_t(15);
 }
+
+int F64FN(state_words_f64)() { return (int)((sizeof(F64NS::Shared) + 15) / 16) * 4; }
 
 size_t F64FN(workspace_doubles_per_wg_f64)(int NBmax, int PCcov) {
     // + V of all prediction chunks when the full covariance is wanted (spare chunks: a wave always solves 2 at a time)

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gpsat_amd.engine import Engine
 from gpsat_amd import synthetic as syn
-T, N, P, D = int(os.environ.get("T", 512)), int(os.environ.get("N", 500)), 500, 3
+T, N, P, D = int(os.environ.get("T", 4096)), int(os.environ.get("N", 500)), 500, 3
 b = syn.make_batch(32, N, P, D, 0, base_seed=1, dtype=np.float64)
 rep = T // 32
 X, y, Xs = np.tile(b["X"], (rep, 1)), np.tile(b["y"], rep), np.tile(b["Xs"], (rep, 1))
