@@ -98,9 +98,6 @@ __device__ __forceinline__ f32x16 pack16(const f32x4& a, const f32x4& b, const f
 
 // global block `blk` of the workgroup's workspace
 __device__ __forceinline__ f32x16 ldg(const float* __restrict__ ws, int blk, int lane) {
-#ifdef GPSAT_EXP_CACHED          // experiment: every operand block load hits one of 8 blocks (results are garbage)
-    blk &= 7;
-#endif
     const f32x4* q = reinterpret_cast<const f32x4*>(ws + (size_t)blk * BLK) + lane;
     return pack16(q[0], q[64], q[128], q[192]);
 }
@@ -127,20 +124,8 @@ __device__ __forceinline__ void stl(int off, int lane, const f32x16& v) {
 
 // acc += S_A^T * S_B   (16 x v_mfma_f32_32x32x2_f32)
 __device__ __forceinline__ void mma_blk(f32x16& acc, const f32x16& a, const f32x16& b) {
-#if GPSAT_EXP_ABL == 3           // ablation: half of the MFMAs
-    for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s] + a[s + 8], b[s], acc, 0, 0, 0);
-#elif GPSAT_EXP_ABL == 4         // ablation: one MFMA per block product (the skeleton without the matrix work)
-    float sa = 0.f, sb = 0.f;
-    for (int s = 0; s < 16; ++s) { sa += a[s]; sb += b[s]; }
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sa, sb, acc, 0, 0, 0);
-    return;
-#elif GPSAT_EXP_ABL == 5         // ablation: 24 MFMAs per block product
-    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
-    for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s + 8], acc, 0, 0, 0);
-#else
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
-#endif
 }
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -209,12 +194,6 @@ __device__ __forceinline__ void kfun(float r2, float& kf, float& gg) {
     }
 }
 
-#ifndef GPSAT_EXP_UNROLL2
-#define GPSAT_EXP_UNROLL2 0      // experiment: k-loops two steps per trip without operand copies (1: sweep, 2: K^-1 phase)
-#endif
-#ifndef GPSAT_EXP_ABL
-#define GPSAT_EXP_ABL 0          // developer ablations (scripts/eval_bench.py); 0 in every shipped build
-#endif
 #define GPSAT_PT_MAXNB 100      // block columns of the largest tile (gpsat_max_tile_obs: 3168 = 99 * 32)
 #include "gpsat_opt.h"
 
@@ -244,9 +223,6 @@ struct Ctx {
 // ---------------------------------------------------------------------------------------------
 template <int D, int KERN>
 __device__ __forceinline__ f32x16 kblock_t(const Ctx<D, KERN>& c, int bi, int bj) {
-#if GPSAT_EXP_ABL == 1           // ablation: no K-block generation
-    { f32x16 o; for (int r = 0; r < 16; ++r) o[r] = (bi == bj && rho(r, c.h) == c.g) ? 2.f : 0.001f; return o; }
-#endif
     const int q = 32 * bj + c.g;
     float xq[D];
 #pragma unroll
@@ -345,9 +321,6 @@ __device__ __forceinline__ f32x16 ksblock(const Ctx<D, KN>& c, int bj, const flo
 template <int D, int KERN>
 __device__ __forceinline__ void contract_t(const Ctx<D, KERN>& c, const f32x16& kinv, int ba, int bb, float wgt,
                                            float (&accl)[D], float& accsf, float& accsn) {
-#if GPSAT_EXP_ABL == 1 || GPSAT_EXP_ABL == 6          // ablation: no contraction
-    accsf += kinv[0]; return;
-#endif
     const int q = 32 * bb + c.g;
     float xq[D];
 #pragma unroll
@@ -461,9 +434,6 @@ __device__ __forceinline__ float lane_xor32(float x, int h) {
 __device__ __forceinline__ void diag_factor(const f32x16& W, int Ad, int piv, int lane, f32x16& S1, f32x16& S2,
                                             double& logsum, int& bad) {
     const int h = lane >> 5, g = lane & 31;
-#if GPSAT_EXP_ABL == 2           // ablation: no factorisation
-    S1 = W; S2 = W; logsum = 0.0; bad = 0; return;
-#endif
     f32x16 TA = W;
     f32x16 TE;
 #pragma unroll
@@ -483,9 +453,6 @@ __device__ __forceinline__ void diag_factor(const f32x16& W, int Ad, int piv, in
         float p11 = readlane_f(TA[r1], 32 * hp + k1);
         float det = p00 * p11 - p10 * p10;
         if (!(p00 > 0.f) || !(det > 0.f)) { isbad = 1; p00 = 1.f; p10 = 0.f; p11 = 1.f; det = 1.f; }
-#if defined(GPSAT_EXP_CACHED) || GPSAT_EXP_ABL
-        isbad = 0;
-#endif
         float rd = __builtin_amdgcn_rcpf(det);
         rd = rd * (2.f - det * rd);
         const bool mine = lane == s;
@@ -582,75 +549,9 @@ __device__ __forceinline__ void pt_group_kloop(const Ctx<D, KN>& c, const Panel<
     const bool u0 = e0 < p.nU, u1 = e1 < p.nU;
     const int c0 = v0 ? pt_item_col(p, e0) : 0, c1 = v1 ? pt_item_col(p, e1) : 0;
     const int ks0 = v0 ? (u0 ? 0 : c0) : j0, ks1 = v1 ? (u1 ? 0 : c1) : j0;
-#if GPSAT_EXP_ABL == 8           // ablation: no k-loops
-    const int kmin = j0;
-#else
     const int kmin = min(ks0, ks1);
-#endif
 #pragma unroll
     for (int n = 0; n < 4; ++n) W[n] = zero16();
-#ifdef GPSAT_EXP_INPLACE        // experiment E13': slower by 1.2 % (the refill has 2048 instead of 4096 MFMA cycles to arrive)
-    if (kmin < j0) {
-        // Operand registers are refilled IN PLACE as soon as their last product of the step has issued (each then has two
-        // block products = 2048 MFMA cycles to arrive); only B0, used by the last and the first product, keeps a spare set.
-        // No register copies besides those 16 (a v_mov costs the f32 MFMA pipe its issue slot, see kfun).
-        f32x16 A0 = ldg(c.ws, kmin * NB + j0, lane);
-        f32x16 A1 = ldg(c.ws, p.has1 ? kmin * NB + p.j1 : c.zb, lane);
-        f32x16 B0 = ldg(c.ws, (kmin >= ks0) ? kmin * NB + c0 : c.zb, lane);
-        f32x16 B1 = ldg(c.ws, (kmin >= ks1) ? kmin * NB + c1 : c.zb, lane);
-        for (int k = kmin; k < j0; ++k) {
-            const int kn = min(k + 1, j0 - 1);          // the last step reloads its own blocks (harmless)
-            const f32x16 nB0 = ldg(c.ws, (kn >= ks0) ? kn * NB + c0 : c.zb, lane);
-            mma_blk(W[0], A0, B0);
-            mma_blk(W[1], A0, B1);
-            __builtin_amdgcn_sched_barrier(0);
-            A0 = ldg(c.ws, kn * NB + j0, lane);
-            mma_blk(W[3], A1, B1);
-            __builtin_amdgcn_sched_barrier(0);
-            B1 = ldg(c.ws, (kn >= ks1) ? kn * NB + c1 : c.zb, lane);
-            mma_blk(W[2], A1, B0);
-            __builtin_amdgcn_sched_barrier(0);
-            A1 = ldg(c.ws, p.has1 ? kn * NB + p.j1 : c.zb, lane);
-            B0 = nB0;
-        }
-    }
-#elif (GPSAT_EXP_UNROLL2 & 1)  // experiment E12': two k-steps per trip, the operand sets swap roles (no copies)
-    if (kmin < j0) {
-        f32x16 A0 = ldg(c.ws, kmin * NB + j0, lane);
-        f32x16 A1 = ldg(c.ws, p.has1 ? kmin * NB + p.j1 : c.zb, lane);
-        f32x16 B0 = ldg(c.ws, (kmin >= ks0) ? kmin * NB + c0 : c.zb, lane);
-        f32x16 B1 = ldg(c.ws, (kmin >= ks1) ? kmin * NB + c1 : c.zb, lane);
-        int k = kmin;
-        for (; k + 1 < j0; k += 2) {
-            const int kn = k + 1;
-            const f32x16 Y0 = ldg(c.ws, kn * NB + j0, lane);
-            const f32x16 Y1 = ldg(c.ws, p.has1 ? kn * NB + p.j1 : c.zb, lane);
-            const f32x16 Z0 = ldg(c.ws, (kn >= ks0) ? kn * NB + c0 : c.zb, lane);
-            const f32x16 Z1 = ldg(c.ws, (kn >= ks1) ? kn * NB + c1 : c.zb, lane);
-            mma_blk(W[0], A0, B0);
-            mma_blk(W[1], A0, B1);
-            mma_blk(W[2], A1, B0);
-            mma_blk(W[3], A1, B1);
-            __builtin_amdgcn_sched_barrier(0);
-            const int km = min(k + 2, j0 - 1);
-            A0 = ldg(c.ws, km * NB + j0, lane);
-            A1 = ldg(c.ws, p.has1 ? km * NB + p.j1 : c.zb, lane);
-            B0 = ldg(c.ws, (km >= ks0) ? km * NB + c0 : c.zb, lane);
-            B1 = ldg(c.ws, (km >= ks1) ? km * NB + c1 : c.zb, lane);
-            mma_blk(W[0], Y0, Z0);
-            mma_blk(W[1], Y0, Z1);
-            mma_blk(W[2], Y1, Z0);
-            mma_blk(W[3], Y1, Z1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (k < j0) {
-            mma_blk(W[0], A0, B0);
-            mma_blk(W[1], A0, B1);
-            mma_blk(W[2], A1, B0);
-            mma_blk(W[3], A1, B1);
-        }
-    }
-#else
     if (kmin < j0) {
         f32x16 A0 = ldg(c.ws, kmin * NB + j0, lane);
         f32x16 A1 = ldg(c.ws, p.has1 ? kmin * NB + p.j1 : c.zb, lane);
@@ -675,7 +576,6 @@ __device__ __forceinline__ void pt_group_kloop(const Ctx<D, KN>& c, const Panel<
         mma_blk(W[2], A1, B0);
         mma_blk(W[3], A1, B1);
     }
-#endif
     // U-type: W = K - acc ; M-type: W = -acc
     if (v0 && u0) {
         W[0] = kblock<D, KN>(c, j0, c0) - W[0];
@@ -714,7 +614,7 @@ __device__ __forceinline__ void pt_group_row(const Ctx<D, KN>& c, const Panel<D>
             f32x16 X = zero16();
             mma_blk(X, Lop, src);
             stg(c.ws, jr * NB + col, lane, X);          // U-type: upper slot (jr,col); M-type: lower slot
-            if (!isu && GPSAT_EXP_ABL != 7) {
+            if (!isu) {
                 float ap = 0.f;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) ap = fmaf(X[q], lds_f[c.L.z + 32 * jr + rho(q, c.h)], ap);
@@ -1142,7 +1042,7 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
             f32x16 B0 = ldg(c.ws, a0 * NB + b0, lane);
             f32x16 B1 = ldg(c.ws, use01 ? a0 * NB + b1 : c.zb, lane);
             f32x16 A1 = A0;
-            if (a0 + 1 < NB && GPSAT_EXP_ABL != 8) {
+            if (a0 + 1 < NB) {
                 f32x16 nA0 = ldg(c.ws, a1 * NB + a0, lane);
                 f32x16 nA1 = ldg(c.ws, a1 * NB + a1, lane);
                 f32x16 nB0 = ldg(c.ws, a1 * NB + b0, lane);
@@ -1150,54 +1050,6 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
                 mma_blk(acc[0], A0, B0);
                 if (use01) mma_blk(acc[1], A0, B1);
                 A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
-#ifdef GPSAT_EXP_INPLACE
-                for (int cc = a1; cc < NB; ++cc) {
-                    // in-place operand refill, as in pt_group_kloop
-                    const int cn = min(cc + 1, NB - 1);
-                    nB0 = ldg(c.ws, cn * NB + b0, lane);
-                    mma_blk(acc[0], A0, B0);
-                    if (use01) mma_blk(acc[1], A0, B1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    A0 = ldg(c.ws, cn * NB + a0, lane);
-                    if (hasb1) mma_blk(acc[3], A1, B1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    B1 = ldg(c.ws, hasb1 ? cn * NB + b1 : c.zb, lane);
-                    mma_blk(acc[2], A1, B0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    A1 = ldg(c.ws, cn * NB + a1, lane);
-                    B0 = nB0;
-                }
-#elif (GPSAT_EXP_UNROLL2 & 2)
-                int cc = a1;
-                for (; cc + 1 < NB; cc += 2) {
-                    const int cn = cc + 1;
-                    nA0 = ldg(c.ws, cn * NB + a0, lane);
-                    nA1 = ldg(c.ws, cn * NB + a1, lane);
-                    nB0 = ldg(c.ws, cn * NB + b0, lane);
-                    nB1 = ldg(c.ws, hasb1 ? cn * NB + b1 : c.zb, lane);
-                    mma_blk(acc[0], A0, B0);
-                    if (use01) mma_blk(acc[1], A0, B1);
-                    mma_blk(acc[2], A1, B0);
-                    if (hasb1) mma_blk(acc[3], A1, B1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    const int cm = min(cc + 2, NB - 1);
-                    A0 = ldg(c.ws, cm * NB + a0, lane);
-                    A1 = ldg(c.ws, cm * NB + a1, lane);
-                    B0 = ldg(c.ws, cm * NB + b0, lane);
-                    B1 = ldg(c.ws, hasb1 ? cm * NB + b1 : c.zb, lane);
-                    mma_blk(acc[0], nA0, nB0);
-                    if (use01) mma_blk(acc[1], nA0, nB1);
-                    mma_blk(acc[2], nA1, nB0);
-                    if (hasb1) mma_blk(acc[3], nA1, nB1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (cc < NB) {
-                    mma_blk(acc[0], A0, B0);
-                    if (use01) mma_blk(acc[1], A0, B1);
-                    mma_blk(acc[2], A1, B0);
-                    if (hasb1) mma_blk(acc[3], A1, B1);
-                }
-#else
                 for (int cc = a1; cc + 1 < NB; ++cc) {          // last step peeled, as in pt_group_kloop
                     const int cn = cc + 1;
                     nA0 = ldg(c.ws, cn * NB + a0, lane);
@@ -1214,7 +1066,6 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
                 if (use01) mma_blk(acc[1], A0, B1);
                 mma_blk(acc[2], A1, B0);
                 if (hasb1) mma_blk(acc[3], A1, B1);
-#endif
             } else {
                 mma_blk(acc[0], A0, B0);
                 if (use01) mma_blk(acc[1], A0, B1);
@@ -1551,8 +1402,10 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
         if (resumed) {
             // The state was written by another workgroup, possibly on another XCD (whose L2 is not coherent with this one).
             // It travels through agent-scope atomic word accesses, which go to memory past the caches: no cache-wide
-            // write-back / invalidate (an agent-scope fence costs every workgroup of the XCD its L2 contents).  The writer's
-            // stores had completed (vmcnt 0 + barrier) before it published the ring entry this workgroup has seen.
+            // write-back / invalidate (an agent-scope fence costs every workgroup of the XCD its L2 contents).  Every wave of
+            // the writer had drained its stores (s_waitcnt vmcnt(0)) and met the workgroup barrier before one lane published
+            // the ring entry that this workgroup's thread 0 has polled (sc1 load) ahead of the barrier above; every load of
+            // the state is an sc1 load to registers (MI355X_MICROARCH.md, inter-workgroup visibility: valid forms).
             const unsigned* src = A.state + (size_t)t * A.state_words;
             unsigned* dst = reinterpret_cast<unsigned*>(sh);
             for (int i = c.tid; i < A.state_words; i += NT)
@@ -1595,7 +1448,9 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
             const unsigned* src = reinterpret_cast<const unsigned*>(sh);
             for (int i = c.tid; i < A.state_words; i += NT)
                 __hip_atomic_store(&dst[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // every wave: its stores have completed (vmcnt 0)
+            // EVERY storing wave drains its own stores (a workgroup-scope fence emits no vmcnt wait on gfx950; inline asm
+            // so that no compiler pass can drop or move it), THEN the barrier, THEN one lane publishes the ring entry
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (c.tid == 0) ring_push(A, t);
             continue;

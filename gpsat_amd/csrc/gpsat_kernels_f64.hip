@@ -931,7 +931,8 @@ __global__ void __launch_bounds__(NT, F64_MIN_WG) gp_tile_kernel_f64(const Kerne
             const unsigned* src = reinterpret_cast<const unsigned*>(sh);
             for (int i = c.tid; i < A.state_words; i += NT)
                 __hip_atomic_store(&dst[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            // every storing wave drains its own stores, then the barrier, then one lane publishes (see gpsat_kernels.hip)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (c.tid == 0) ring_push(A, t);
             continue;

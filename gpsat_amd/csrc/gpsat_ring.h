@@ -16,8 +16,8 @@ static __device__ __forceinline__ int ring_pop(const KernelArgs& A) {
     const unsigned s = (unsigned)__hip_atomic_fetch_add(&A.ring_ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long* e = A.ring + (s & (unsigned)A.ring_mask);
     for (int spins = 0;; ++spins) {
-        // relaxed polling: an agent-scope acquire invalidates the XCD's L2 each time, which every other workgroup pays for;
-        // the one acquire a resumed tile needs is the fence before its state is read (gp_tile_kernel)
+        // relaxed sc1 polling, no acquire fence anywhere: a resumed tile's state is read with sc1 loads only (they bypass
+        // this CU's L1), after the workgroup barrier that follows this poll (gp_tile_kernel)
         const unsigned long long v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(v >> 32) == s + 1u) return (int)(unsigned)v;
         // nothing there yet: either a tile will be pushed back, or every tile is finished

@@ -1,10 +1,16 @@
 #!/bin/bash
 # Developer: build the current working tree's fp32 kernels into gpsat_amd/csrc/libgpsat_hip_<TAG>.so (the other objects
 # are taken as they are), for A/B runs in ONE gpurun call (boxes differ by a few per cent):
-#   scripts/build_variant.sh TAG [extra hipcc flags]
+#   scripts/build_variant.sh TAG [--patch scripts/experiments/X.patch] [extra hipcc flags]
+# --patch applies a developer patch (scripts/experiments/) to the kernel sources for this build only and reverts it.
 set -e
 TAG=$1; shift
-cd "$(dirname "$0")/../gpsat_amd/csrc"
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+PATCH=""
+if [ "$1" = "--patch" ]; then PATCH="$(realpath "$2")"; shift 2; fi
+cd "$ROOT"
+if [ -n "$PATCH" ]; then patch -p1 < "$PATCH"; trap 'cd "$ROOT" && patch -R -p1 < "$PATCH"' EXIT; fi
+cd "$ROOT/gpsat_amd/csrc"
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -I. -Wno-unused-function"
 /opt/rocm/bin/hipcc $F "$@" -c gpsat_kernels.hip -o /tmp/v_${TAG}_k.o &
 /opt/rocm/bin/hipcc $F "$@" -DGPSAT_W8 -c gpsat_kernels.hip -o /tmp/v_${TAG}_k8.o &
