@@ -232,6 +232,36 @@ def predict_cov(kid, X, y, Xs, theta):
 
 
 # --------------------------------------------------------------------------
+# Adam (Kingma & Ba 2015, Algorithm 1) as torch.optim.Adam computes it -- the optimiser of the reference's Adam path
+# (GPSat/models/gpytorch_models.py:187-199: torch.optim.Adam(lr=0.1), defaults betas (0.9, 0.999), eps 1e-8, one
+# gradient evaluation per step).  Pinned against torch.optim.Adam itself in tests/test_oracle_golden.py.
+# --------------------------------------------------------------------------
+def adam_minimise(fun, u0, steps, lr=0.1, b1=0.9, b2=0.999, eps=1e-8):
+    """fun(u) -> (f, g).  ``steps`` updates: u_k = u_{k-1} - lr * m_hat / (sqrt(v_hat) + eps) with the gradient at
+    u_{k-1}; steps + 1 evaluations in all (the last one at the returned point).  A non-finite objective ends the run at
+    the previous iterate.  Returns (u, ok, trajectory [steps + 1, len(u)])."""
+    u = np.array(u0, dtype=np.float64)
+    m = np.zeros_like(u)
+    v = np.zeros_like(u)
+    traj = [u.copy()]
+    f, g = fun(u)
+    if not np.isfinite(f):
+        return u, False, np.array(traj)
+    for k in range(1, steps + 1):
+        m = b1 * m + (1.0 - b1) * g
+        v = b2 * v + (1.0 - b2) * g * g
+        mh = m / (1.0 - b1 ** k)
+        vh = v / (1.0 - b2 ** k)
+        un = u - lr * mh / (np.sqrt(vh) + eps)
+        f, gn = fun(un)
+        if not np.isfinite(f):
+            return u, False, np.array(traj)
+        u, g = un, gn
+        traj.append(u.copy())
+    return u, True, np.array(traj)
+
+
+# --------------------------------------------------------------------------
 # the per-tile model: defaults, constraints, optimise, predict
 # --------------------------------------------------------------------------
 class OracleGPR:
@@ -362,6 +392,39 @@ class OracleGPR:
         self.theta = th
         self.opt_result = res
         return bool(res.success)
+
+    def optimise_parameters_adam(self, max_iter=20, lr=0.1, fixed_params=None):
+        """Exactly ``max_iter`` Adam steps on the unconstrained u of the trainable entries (``adam_minimise`` below).
+        The reference's Adam path is ``torch.optim.Adam(lr=0.1)`` over the model parameters
+        (GPSat/models/gpytorch_models.py:187-199); BASELINE.json's north_star names "20 L-BFGS/Adam steps".  Here it runs on
+        this model's objective and transforms.  Returns False when an evaluation met a non-positive-definite K (the
+        iterate before it is kept), else True."""
+        D = self.D
+        trainable = np.ones(D + 2, dtype=bool)
+        for p in (fixed_params or []):
+            trainable[self._slice(p)] = False
+        self.n_eval = 0
+        u_all = u_from_theta(self.theta, self.lo, self.hi, self.shift)
+
+        def fun(u_tr):
+            u = u_all.copy()
+            u[trainable] = u_tr
+            th = theta_from_u(u, self.lo, self.hi, self.shift)
+            th[~trainable] = self.theta[~trainable]
+            f, g = nll_and_grad(self.kid, self.coords, self.obs[:, 0], th)
+            self.n_eval += 1
+            if not np.isfinite(f):
+                return np.inf, np.zeros(trainable.sum())
+            return f, (g * dtheta_du(th, self.lo, self.hi, self.shift))[trainable]
+
+        u_tr, ok, traj = adam_minimise(fun, u_all[trainable], max_iter, lr)
+        u = u_all.copy()
+        u[trainable] = u_tr
+        th = theta_from_u(u, self.lo, self.hi, self.shift)
+        th[~trainable] = self.theta[~trainable]
+        self.theta = th
+        self.adam_trajectory = traj
+        return ok
 
     def predict(self, coords, full_cov=False, apply_scale=True):
         coords = np.asarray(coords, dtype=np.float64)

@@ -183,3 +183,41 @@ def test_sklearn_optimum_d3(golden_dir, name, kid):
     f, fv, _ = go.predict(kid, X, y, Xs, th)
     np.testing.assert_allclose(f, g[f"{name}_50_opt_mean"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(np.sqrt(fv), g[f"{name}_50_opt_std"], rtol=0, atol=1e-4)
+
+
+def test_adam_matches_torch_optim_adam():
+    """The oracle's Adam is torch.optim.Adam -- the optimiser of the reference's Adam path
+    (GPSat/models/gpytorch_models.py:187-199: torch.optim.Adam(lr=0.1), one gradient per step) -- step for step, on the
+    oracle's own objective and transforms (20 steps, D = 3 ARD, box-constrained length scales)."""
+    import torch
+    from gpsat_amd import synthetic as syn
+    X, y, _, _ = syn.make_tile(77, 60, 0, 3, 0)
+    lo = np.array([1e-8, 1e-8, 1e-8, -np.inf, -np.inf])
+    hi = np.array([12.0, 12.0, 9.0, np.inf, np.inf])
+    shift = np.array([0, 0, 0, 0, go.LIK_VAR_LOWER])
+    u0 = go.u_from_theta(np.ones(5), lo, hi, shift)
+
+    def fun(u):
+        th = go.theta_from_u(u, lo, hi, shift)
+        f, g = go.nll_and_grad(0, X, y, th)
+        return f, g * go.dtheta_du(th, lo, hi, shift)
+
+    u, ok, traj = go.adam_minimise(fun, u0, 20, lr=0.1)
+    assert ok and traj.shape == (21, 5)
+    p = torch.tensor(u0, dtype=torch.float64, requires_grad=True)
+    opt = torch.optim.Adam([p], lr=0.1)
+    for k in range(20):
+        opt.zero_grad()
+        p.grad = torch.tensor(fun(p.detach().numpy())[1])
+        opt.step()
+        np.testing.assert_allclose(traj[k + 1], p.detach().numpy(), rtol=1e-12, atol=1e-13)
+    assert fun(u)[0] < fun(u0)[0]
+
+
+def test_adam_model_method_counts_evaluations():
+    from gpsat_amd import synthetic as syn
+    X, y, _, _ = syn.make_tile(5, 40, 0, 2, 2)
+    m = go.OracleGPR(X, y, kernel="Matern32")
+    f0 = m.get_objective_function_value()
+    assert m.optimise_parameters_adam(max_iter=7, lr=0.05, fixed_params=["likelihood_variance"])
+    assert m.n_eval == 8 and m.theta[3] == 1.0 and m.get_objective_function_value() < f0
