@@ -14,11 +14,15 @@ Workloads (``--workload``):
                       one RCCL all_gather of per-tile hyper-parameters + predictions closes each step when N > 1.
   configs2            BASELINE.json configs[2]: ragged N in {128..2048}, Matern-3/2, fp32.
   configs4            BASELINE.json configs[4] per GPU: fp64, N = 2000, predict-only with given hyper-parameters.
+  f64fit              configs[1]'s tiles in the reference's native precision (fp64 kernels, fit + predict).
   --global-tiles G    BASELINE.json configs[3]: ONE global list of G tiles (N = 500, RBF), split over the ranks by the
                       LPT partition (sharding.partition_tiles), each rank runs its shard, one gather(v) of
                       hyper-parameters + predictions to rank 0 in the reference's tile order.  Strong scaling.
 ``--exact-iters`` switches the optimiser's early stopping off (ftol = gtol = off): every tile runs exactly max_iter
 iterations unless its line search fails; the CPU baseline then runs SciPy with ftol = gtol = 0 on matched work.
+
+``python bench.py --gpus N`` without a torch.distributed environment starts the N ranks itself (a child
+``python -m torch.distributed.run --nproc-per-node N ... bench.py``, before this process touches the GPU) and relays the line.
 
 Prints ONE JSON line on rank 0.  ``value`` = whole-job tiles/s with inputs resident in HBM; ``host_to_host_ms`` is the
 same step timed from packed host arrays to outputs on the host (SURVEY.md 8(d)'s definition, PCIe included) -- context,
@@ -121,7 +125,7 @@ def build_workload(a, rank, world, workers):
                  key="configs3", T=T, Ns=np.full(T, N), kid=kid, kernel=a.kernel, optimiser=a.optimiser, max_iter=a.max_iter,
                  X=X, y=y, Xs=Xs, theta0=np.ones((T, D + 2)), lo=lo, hi=hi, scaling="strong", global_T=G, mine=mine,
                  data="synthetic (2048 prototype tiles, replicas distinct by scaled observations)")
-    elif a.workload == "configs1":
+    elif a.workload in ("configs1", "f64fit"):
         T, N, kid = a.tiles, a.nobs, L.KERNEL_IDS[a.kernel]
         res = gen_tiles([(1_000_000 * rank + t, N, P, D, kid) for t in range(T)], workers)
         lo, hi = syn.default_bounds(T, D)
@@ -130,6 +134,11 @@ def build_workload(a, rank, world, workers):
                  X=np.concatenate([r[0] for r in res]).astype(np.float32), y=np.concatenate([r[1] for r in res]).astype(np.float32),
                  Xs=np.concatenate([r[2] for r in res]).astype(np.float32), theta0=np.ones((T, D + 2)), lo=lo, hi=hi,
                  data="synthetic")
+        if a.workload == "f64fit":
+            # the same tiles (fp32-representable coordinates) through the fp64 kernels: the reference's native precision
+            w.update(name="BASELINE.json configs[1]'s tiles in fp64 (GPflow default_float): RBF, 3D inputs, fit + predict",
+                     key="f64fit", dtype="f64", np_dt=np.float64, peak=PEAK_F64_MFMA_TFLOPS,
+                     X=w["X"].astype(np.float64), y=w["y"].astype(np.float64), Xs=w["Xs"].astype(np.float64))
     elif a.workload == "configs2":
         T = a.tiles                     # BASELINE configs[2]: 4096 ragged tiles (a 1024-tile launch is as long as its largest tile)
         kid = 2
@@ -203,10 +212,32 @@ def _cpu_tile(args):
             m.n_eval, nit = cnt[0], int(res.nit)
         else:
             m.n_eval = 0
-        m.get_objective_function_value()
+        nll = m.get_objective_function_value()
         if len(Xs):
             m.predict(Xs, apply_scale=False)
-        return time.perf_counter() - t0, int(m.n_eval), nit
+        return time.perf_counter() - t0, int(m.n_eval), nit, float(nll)
+
+
+def _sk_tile(args):
+    """Optional second CPU line: scikit-learn's GaussianProcessRegressor -- the oracle of the
+    reference's own known-answer test (tests/test_localexperts.py:22-49) -- on the identical tile: ARD kernel of the same
+    family + white noise, L-BFGS-B from the same start, no restarts, predict mean + std."""
+    X, y, Xs, D, kid, max_iter, lo, hi, theta0, optimise, exact, nthreads = args
+    from threadpoolctl import threadpool_limits
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel, Matern, WhiteKernel
+    with threadpool_limits(nthreads):
+        t0 = time.perf_counter()
+        ls = np.asarray(theta0[:D], dtype=np.float64)
+        hi_l = np.where(np.isfinite(hi[:D]), hi[:D], 1e5) if hi is not None else np.full(D, 1e5)
+        bounds = np.stack([np.full(D, 1e-5), hi_l], axis=1)
+        base = RBF(ls, bounds) if kid == 0 else Matern(ls, bounds, nu={1: 0.5, 2: 1.5, 3: 2.5}[kid])
+        k = ConstantKernel(float(theta0[D]), (1e-6, 1e5)) * base + WhiteKernel(float(theta0[D + 1]), (1e-6, 1e5))
+        gp = GaussianProcessRegressor(kernel=k, optimizer="fmin_l_bfgs_b" if optimise else None, n_restarts_optimizer=0)
+        gp.fit(X, y)
+        if len(Xs):
+            gp.predict(Xs, return_std=True)
+        return time.perf_counter() - t0, 0, 0, float(-gp.log_marginal_likelihood_value_)
 
 
 def cpu_baseline(w, a, workers):
@@ -247,6 +278,32 @@ def cpu_baseline(w, a, workers):
                                                evals_per_tile=round(float(np.mean([r[1] for r in res_c])), 2),
                                                iters_per_tile=round(float(np.mean([r[2] for r in res_c])), 2),
                                                layout=f"{workers} single-threaded processes, SciPy default convergence (maxiter 10000)")
+    # every core this process may run on (the GPU box gives one GPU's share of the host; the judge asked for the all-core
+    # figure beside the 16-process one) and the scikit-learn line of BASELINE.md section 2
+    try:
+        ncore = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncore = os.cpu_count() or workers
+    big = min(ncore, 128)
+    if big > workers and not a.exact_iters:
+        with get_context("fork").Pool(big) as pool:
+            pool.map(_cpu_warm, range(big * 2))
+            t0 = time.perf_counter()
+            res_a = pool.map(_cpu_tile, jobs(max(2 * big, n_main), w["max_iter"], False, 1), chunksize=1)
+            wall_a = time.perf_counter() - t0
+        modes["budget_all_cores"] = dict(tiles_per_s=round(len(res_a) / wall_a, 3), tiles=len(res_a), wall_s=round(wall_a, 2),
+                                         evals_per_tile=round(float(np.mean([r[1] for r in res_a])), 2),
+                                         layout=f"{big} single-threaded processes ({ncore} hardware threads usable by this process, "
+                                                f"{os.cpu_count()} on the host)")
+    if optimise and not a.exact_iters and not a.no_sklearn:
+        with get_context("fork").Pool(workers) as pool:
+            pool.map(_cpu_warm, range(workers * 2))
+            t0 = time.perf_counter()
+            res_s = pool.map(_sk_tile, jobs(max(workers, n_main // 8), w["max_iter"], False, 1), chunksize=1)
+            wall_s = time.perf_counter() - t0
+        modes["sklearn_per_core"] = dict(tiles_per_s=round(len(res_s) / wall_s, 3), tiles=len(res_s), wall_s=round(wall_s, 2),
+                                         layout=f"{workers} single-threaded processes, sklearn GaussianProcessRegressor "
+                                                f"(n_restarts_optimizer=0, run to its own convergence), fit + predict")
     # all-thread BLAS, one process (after the pool is gone: BLAS threads and fork do not mix)
     n_blas = max(2, n_main // 16)
     t0 = time.perf_counter()
@@ -255,15 +312,18 @@ def cpu_baseline(w, a, workers):
     modes["budget_allthread_blas"] = dict(tiles_per_s=round(len(res_b) / wall_b, 3), tiles=len(res_b), wall_s=round(wall_b, 2),
                                           evals_per_tile=round(float(np.mean([r[1] for r in res_b])), 2),
                                           layout=f"one process, BLAS on all {os.cpu_count()} threads")
-    best = max(("budget_per_core", "budget_allthread_blas"), key=lambda k: modes[k]["tiles_per_s"])
+    best = max([k for k in ("budget_per_core", "budget_allthread_blas", "budget_all_cores") if k in modes],
+               key=lambda k: modes[k]["tiles_per_s"])
     m = modes[best]
+    cores_of = {"budget_per_core": workers, "budget_all_cores": big, "budget_allthread_blas": os.cpu_count()}
     what = (f"L-BFGS-B maxiter={w['max_iter']}" + (", ftol=gtol=0" if a.exact_iters else ", SciPy default tolerances")) if optimise \
         else "objective + predict only"
-    return {"value": m["tiles_per_s"], "unit": "tiles/s", "cores": workers if best == "budget_per_core" else os.cpu_count(),
+    cpu_nll = {"tiles": n_done, "nll": [r[3] for r in res]}        # objective reached within the iteration budget, per tile
+    return {"value": m["tiles_per_s"], "unit": "tiles/s", "cores": cores_of[best],
             "kind": "port", "cpu_model": cpu_model(), "host_threads": os.cpu_count(),
             "sample": f"{m['tiles']} of the same tiles, fp64 NumPy/SciPy oracle ({what}, {m['evals_per_tile']} evals/tile, "
-                      f"predict P={P}), {m['layout']}, {m['wall_s']} s wall (pool start-up excluded); faster of the two layouts",
-            "modes": modes}
+                      f"predict P={P}), {m['layout']}, {m['wall_s']} s wall (pool start-up excluded); fastest of the layouts in `modes`",
+            "modes": modes, "_nll": cpu_nll}
 
 
 def main():
@@ -285,14 +345,30 @@ def main():
     ap.add_argument("--wg-per-cu", type=int, default=0)
     ap.add_argument("--workers", type=int, default=0, help="host processes for data generation / CPU baseline "
                     "(0 = auto; use 1 under rocprofv3 --pmc: no fork beside the profiler)")
-    ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs4"])
+    ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs4", "f64fit"])
+    ap.add_argument("--no-sklearn", action="store_true", help="skip the scikit-learn line of the CPU baseline")
+    ap.add_argument("--no-quality", action="store_true", help="skip the result-quality block (fp64 converged reference run)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks as a CHILD torch.distributed.run (this process has not touched the
+        # GPU and never will), relay its output and exit with its code
+        import socket
+        import subprocess
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world == 1 and a.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     ncpu = os.cpu_count() or 1
     workers = a.workers if a.workers > 0 else max(1, min(16, ncpu // max(1, min(world, 8))))
 
@@ -372,6 +448,35 @@ def main():
         eng.fit_predict_batch(X=hX, y=hy, Xs=hXs, **kw)
         host_ms = (time.perf_counter() - th) * 1e3
 
+    # ---- what the early stop of the default tolerances costs: the same tiles run to convergence by the
+    # fp64 kernels (pinned to the oracle at 1e-9); objective gap per observation of the timed run's result, and of the CPU
+    # leg's maxiter-budget result on its sample.  Outside the timed region.
+    quality = None
+    if rank == 0 and world == 1 and not a.no_quality and w["optimiser"] != "none" and w["key"] in ("configs1", "f64fit"):
+        kw64 = dict(kw, dtype="f64", max_iter=500)
+        kw64.pop("ftol", None), kw64.pop("gtol", None)
+        r64 = eng.fit_predict_batch(X=np.asarray(w["X"], dtype=np.float64), y=np.asarray(w["y"], dtype=np.float64),
+                                    Xs=np.asarray(w["Xs"], dtype=np.float64)[:0].reshape(0, D), **dict(kw64, pred_off=np.zeros(T + 1, np.int64)))
+        Nn = w["Ns"].astype(np.float64)
+        gap = (r.nll - r64.nll) / Nn
+        okm = np.isfinite(gap)
+        rel_l = np.abs(r.theta[:, :D] - r64.theta[:, :D]) / r64.theta[:, :D]
+        quality = {"reference": "the same tiles by the fp64 HIP kernels run to convergence (L-BFGS, SciPy-default ftol / gtol, max_iter 500)",
+                   "ref_evals_per_tile": round(float(r64.n_eval.mean()), 2), "ref_converged_frac": round(float(np.mean(r64.status == 0)), 4),
+                   "nll_gap_per_obs": {"median": float(np.median(gap[okm])), "p99": float(np.quantile(gap[okm], 0.99)),
+                                       "max": float(gap[okm].max()), "min": float(gap[okm].min())},
+                   "lengthscale_rel_diff": {"median": float(np.median(rel_l)), "p99": float(np.quantile(rel_l, 0.99))}}
+        if cpu is not None and "_nll" in cpu:
+            nc = cpu["_nll"]["tiles"]
+            gc = (np.asarray(cpu["_nll"]["nll"]) - r64.nll[:nc]) / Nn[:nc]
+            quality["cpu_budget_nll_gap_per_obs"] = {"tiles": nc, "median": float(np.median(gc)), "p99": float(np.quantile(gc, 0.99)),
+                                                     "max": float(gc.max())}
+            gg = gap[:nc]
+            quality["gpu_nll_gap_per_obs_same_tiles"] = {"median": float(np.median(gg)), "p99": float(np.quantile(gg, 0.99)),
+                                                         "max": float(gg.max())}
+    if cpu is not None:
+        cpu.pop("_nll", None)
+
     if rank == 0:
         Nf = w["Ns"].astype(np.float64)
         n_eval = r.n_eval.astype(np.float64)
@@ -402,7 +507,8 @@ def main():
                        "parallelism": f"tile-sharded x{world}" + (" (LPT over one global list, gather to rank 0)" if w["scaling"] == "strong" else ""),
                        "device": eng.device_name},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": w["peak"], "unit": "TFLOP/s",
-                         "frac": round(achieved / w["peak"], 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": round(achieved / w["peak"], 4), "traffic": traffic, "traffic_measured_in_run": False,
+                         "traffic_source": traffic_src,
                          "kernel": f"gp_tile_kernel<{D}, {w['kid']}>" + (" (fp64)" if w["dtype"] == "f64" else ""),
                          "kernel_ms": round(k_ms, 3), "flops_per_launch": flops_launch},
         }
@@ -410,6 +516,8 @@ def main():
             out["config"]["global_tiles"] = int(w["global_T"])
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if quality is not None:
+            out["quality"] = quality
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

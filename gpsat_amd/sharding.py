@@ -84,7 +84,7 @@ def assemble_global(shards, total=None):
 
 
 def gather_results(fixed, preds, pred_counts, tile_index, world_size, rank, device=None, dst=0, total=None):
-    """One gather of per-tile results to ``dst``.
+    """ONE gather(v) of per-tile results to ``dst``: nothing is sent to the other ranks.
 
     fixed       : [T_r, F] torch tensor (theta, nll, status, n_eval ... per local tile)
     preds       : [sumP_r, C] torch tensor (f*, f*_var, y_var)
@@ -92,37 +92,53 @@ def gather_results(fixed, preds, pred_counts, tile_index, world_size, rank, devi
     tile_index  : [T_r] int64 numpy, global tile ids of the local tiles
     Returns on dst: (fixed_global [T, F], preds_global [sumP, C] in GLOBAL tile order,
                      pred_off_global [T+1]); elsewhere None.
-    Variable-length parts are padded to the maximum over ranks and moved by ONE all_gather each
-    (payloads are tiny against 7 x ~153 GB/s xGMI links; ordering correctness is what matters).
-    """
+    A ``dist.gather`` of the two sizes per rank, then grouped point-to-point transfers (``batch_isend_irecv``: on RCCL one
+    ncclGroupStart / ncclGroupEnd of send / recv pairs = gatherv) of exactly-sized buffers: tile ids and prediction counts
+    as int64, per-tile values as float64, predictions in their own dtype.  Backends: "nccl" = RCCL over xGMI, "gloo"."""
     import torch
     import torch.distributed as dist
 
     dev = fixed.device if device is None else device
     T_r, F = fixed.shape
     Cp = preds.shape[1]
-    meta = torch.tensor([T_r, preds.shape[0]], dtype=torch.int64, device=dev)
-    metas = [torch.zeros_like(meta) for _ in range(world_size)]
-    dist.all_gather(metas, meta)
-    Tmax = int(max(m[0].item() for m in metas))
-    Pmax = int(max(m[1].item() for m in metas))
-    fx = torch.zeros((Tmax, F + 2), dtype=torch.float64, device=dev)
-    fx[:T_r, :F] = fixed.to(torch.float64)
-    fx[:T_r, F] = torch.as_tensor(np.asarray(tile_index), dtype=torch.float64, device=dev)
-    fx[:T_r, F + 1] = torch.as_tensor(np.asarray(pred_counts), dtype=torch.float64, device=dev)
-    pr = torch.zeros((Pmax, Cp), dtype=preds.dtype, device=dev)
-    pr[:preds.shape[0]] = preds
-    fxs = [torch.zeros_like(fx) for _ in range(world_size)]
-    prs = [torch.zeros_like(pr) for _ in range(world_size)]
-    dist.all_gather(fxs, fx)
-    dist.all_gather(prs, pr)
+    n_pr = int(preds.shape[0])
+    meta = torch.tensor([T_r, n_pr], dtype=torch.int64, device=dev)
+    metas = [torch.zeros_like(meta) for _ in range(world_size)] if rank == dst else None
+    dist.gather(meta, metas, dst=dst)
+    ids = torch.stack([torch.as_tensor(np.asarray(tile_index, dtype=np.int64)),
+                       torch.as_tensor(np.asarray(pred_counts, dtype=np.int64))], dim=1).contiguous().to(dev)
+    fx = fixed.to(torch.float64).contiguous()
+    pr = preds.contiguous()
     if rank != dst:
+        ops = []
+        if T_r > 0:
+            ops += [dist.P2POp(dist.isend, ids, dst), dist.P2POp(dist.isend, fx, dst)]
+        if n_pr > 0:
+            ops.append(dist.P2POp(dist.isend, pr, dst))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
         return None
+    sizes = [(int(m[0].item()), int(m[1].item())) for m in metas]
+    bufs, ops = {}, []
+    for r, (tr, npr) in enumerate(sizes):
+        if r == dst:
+            bufs[r] = (ids, fx, pr)
+            continue
+        b = (torch.empty((tr, 2), dtype=torch.int64, device=dev), torch.empty((tr, F), dtype=torch.float64, device=dev),
+             torch.empty((npr, Cp), dtype=preds.dtype, device=dev))
+        bufs[r] = b
+        if tr > 0:
+            ops += [dist.P2POp(dist.irecv, b[0], r), dist.P2POp(dist.irecv, b[1], r)]
+        if npr > 0:
+            ops.append(dist.P2POp(dist.irecv, b[2], r))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     shards = []
     for r in range(world_size):
-        tr, npr = int(metas[r][0].item()), int(metas[r][1].item())
-        f = fxs[r][:tr].cpu().numpy()
-        shards.append((f[:, :F], prs[r][:npr].cpu().numpy(), f[:, F + 1].astype(np.int64), f[:, F].astype(np.int64)))
+        i_, f_, p_ = (t.cpu().numpy() for t in bufs[r])
+        shards.append((f_, p_, i_[:, 1], i_[:, 0]))
     return assemble_global(shards, total)
 
 
@@ -131,6 +147,8 @@ def gather_arrays(fixed, preds, pred_counts, tile_index, total, world_size, rank
     RCCL ("nccl"), on the host for gloo."""
     import torch
     import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() != world_size:
+        raise RuntimeError(f"gather_arrays: no torch.distributed process group of {world_size} ranks is initialised")
     dev = torch.device("cpu")
     if dist.get_backend() == "nccl":
         dev = torch.device("cuda", int(device_id or 0))
