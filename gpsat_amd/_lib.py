@@ -74,8 +74,28 @@ def _one_hip_runtime():
     if os.path.exists(cand):
         try:
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass
+        except OSError as e:
+            import warnings
+            warnings.warn(f"gpsat_amd: could not preload PyTorch's HIP runtime {cand}: {e}; if torch is imported later in this "
+                          f"process it may not see the GPU")
+
+
+def _check_one_hip_runtime():
+    """After libgpsat_hip.so is loaded: the de-duplication above only works when PyTorch's bundled runtime has the SONAME
+    this library was linked against (same ROCm major).  Two different libamdhip64 files mapped into the process = two
+    runtimes: say so instead of failing later with 'No HIP GPUs'."""
+    try:
+        paths = set()
+        for line in open("/proc/self/maps"):
+            if "libamdhip64.so" in line:
+                paths.add(os.path.realpath(line.split()[-1]))
+    except OSError:
+        return
+    if len(paths) > 1:
+        import warnings
+        warnings.warn("gpsat_amd: two HIP runtimes are loaded (" + ", ".join(sorted(paths)) + "): libgpsat_hip.so was built "
+                      "against a ROCm whose libamdhip64 SONAME differs from the one PyTorch bundles.  Build the library with "
+                      "the ROCm release PyTorch was built for (INTEGRATION.md, 'One HIP runtime per process').")
 
 
 def load():
@@ -85,6 +105,7 @@ def load():
             f"or `make -C gpsat_amd/csrc` (there is no CPU fallback)")
     _one_hip_runtime()
     lib = C.CDLL(LIB_PATH)
+    _check_one_hip_runtime()
     for name in EXPORTS:
         if not hasattr(lib, name):
             raise LibraryMissing(f"{LIB_PATH} does not export {name}")

@@ -59,6 +59,7 @@ struct gpsat_handle {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     char name[256] = {0};
     double last_kernel_ms = 0.0, last_total_ms = 0.0;
+    bool force_unsliced = false;       // retry of a batch whose time-sliced queue ended with unfinished tiles
     // device buffers (grown lazily, owned by the handle)
     DevBuf meta_i64, meta_f64, meta_misc, out_f64, out_i32, bulk_in, bulk_out, ws, prof, ring, state;
     DevBuf sel_pts, sel_refs, sel_cnt, sel_idx, sel_box;
@@ -279,6 +280,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
         if (T > grid && max_cost * 4.0 * grid <= sum_cost && tiles_per_wg <= 64.0) seg_cost = 4 * (512 / bs) * (512 / bs) * (512 / bs);
         // developer / tests: slice length in NB^3 units (0 = off, 1 = every evaluation), whatever the batch looks like
         if (const char* e = std::getenv("GPSAT_DEBUG_SEG")) seg_cost = std::max(0, std::atoi(e));
+        if (h->force_unsliced) seg_cost = 0;
     }
     unsigned long long* d_ring = nullptr; int* d_ring_ctl = nullptr; unsigned* d_state = nullptr;
     int ring_mask = 0;
@@ -360,7 +362,16 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     if (seg_cost > 0) HIP_TRY(hipMemcpyAsync(&unfinished, d_ring_ctl + 32, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (unfinished != 0) return fail(GPSAT_EHIP, "time-sliced tile queue ended with " + std::to_string(unfinished) + " unfinished tiles");
+    if (unfinished != 0) {
+        // A queue anomaly (an escape hatch of ring_pop taken: gpsat_ring.h) must not cost the caller the batch: run it again
+        // with every tile run to completion from the plain queue (same results: slicing does not change a bit of them).
+        if (h->force_unsliced) return fail(GPSAT_EHIP, "tile queue ended with " + std::to_string(unfinished) + " unfinished tiles");
+        std::fprintf(stderr, "gpsat: time-sliced tile queue ended with %d unfinished tiles; re-running the batch unsliced\n", unfinished);
+        h->force_unsliced = true;
+        const int rc2 = gpsat_fit_predict_batch(h, b);
+        h->force_unsliced = false;
+        return rc2;
+    }
     float km = 0.f, tm = 0.f;
     HIP_TRY(hipEventElapsedTime(&km, h->ev[1], h->ev[2]));
     HIP_TRY(hipEventElapsedTime(&tm, h->ev[0], h->ev[3]));

@@ -24,8 +24,8 @@ Here the SAME four config dicts are accepted (the in-memory subset listed below)
 
 Tables (``run_details``, ``preds``, ``lengthscales``, ``kernel_variance``, ``likelihood_variance``, ``expert_locs``,
 ``oi_config``; columns ``_dim_0``, ``f*``, ``f*_var``, ``y_var``, ``f_bar``, ``pred_loc_<c>`` ...) carry the expert
-coordinates as (Multi)Index like the reference's.  The store is a directory of pandas-pickled parts (pytables / HDF5
-is not a dependency of this backend).
+coordinates as (Multi)Index like the reference's.  The store is a directory of Apache Parquet parts (pandas pickles
+when pyarrow is absent; pytables / HDF5 is not a dependency of this backend -- ``export_parquet`` / ``export_hdf5``).
 
 Supported config subset (anything else raises ``NotImplementedError`` -- never a silent fallback):
   expert_loc_config : {"source": DataFrame | csv/parquet path, "sort_by": optional col(s)}
@@ -40,8 +40,15 @@ Supported config subset (anything else raises ``NotImplementedError`` -- never a
                                        "index_adjust": {col: {"func": callable | "lambda ..."}}} |
                                       {<param>: value, ...}  (set directly on every tile)}
 ``replacement_*`` model settings for tiles below ``replacement_threshold`` observations are honoured (one engine call
-per model profile and wave).  ``load_params.previous=True`` (an exponential moving average of earlier tiles' optima, a
-serial cross-tile dependency, local_experts.py:1200-1217) is rejected explicitly.
+per model profile and wave).  ``pred_kwargs.full_cov=True`` adds the table ``preds_2`` (``_dim_0``, ``_dim_1``, ``f*_cov``,
+``y_cov``: what ``dict_of_array_to_table(concat=True, table="preds")`` makes of the 2-D arrays of the prediction dict,
+local_experts.py:691-747, gpflow_models.py:245-263).
+``load_params.previous=True`` (local_experts.py:1059-1064,1200-1217: every tile starts from an exponential moving average,
+rho = 0.95, of the optima of the successfully optimised tiles before it) is a serial cross-tile dependency; its batched
+definition here is CALL-LAGGED: all tiles of one engine call start from the average as it stood when the call was
+issued, and the average is then advanced over that call's tiles in expert order.  ``engine_chunk=1`` reproduces the
+reference's serial recurrence exactly; larger chunks trade its freshness for batching (sharded runs keep one average
+per rank).
 """
 from __future__ import annotations
 
@@ -278,33 +285,67 @@ def _index_for(coords_col, loc_rows: np.ndarray):
     return pd.MultiIndex.from_arrays([loc_rows[:, i] for i in range(loc_rows.shape[1])], names=coords_col)
 
 
-_PART_RE = re.compile(r"^(?P<table>.+)\.w(?P<k>\d{6})\.r(?P<r>\d{3})\.pkl$")
+_PART_RE = re.compile(r"^(?P<table>[^.].*)\.w(?P<k>\d{6})\.r(?P<r>\d{3})\.(?P<ext>parquet|pkl)$")
 _MARK_RE = re.compile(r"^_wave\.w(?P<k>\d{6})\.r(?P<r>\d{3})\.ok$")
+_WHOLE_RE = re.compile(r"^(?P<table>[^.].*)\.(?P<ext>parquet|pkl)$")
+
+
+def _have_pyarrow():
+    try:
+        import pyarrow  # noqa: F401
+        return True
+    except Exception:
+        return False
+
+
+def _read_part(path):
+    if path.endswith(".parquet"):
+        df = pd.read_parquet(path)
+        # pandas keeps the (Multi)Index in the parquet metadata; a frame written without rows comes back the same way
+        return df
+    return pd.read_pickle(path)
 
 
 class ResultStore:
-    """Directory store of pandas-pickled tables (no dependency beyond pandas itself; pytables / pyarrow are not
-    guaranteed on the GPU hosts).
+    """Directory store of table parts: Apache Parquet (pyarrow) by default -- readable by ``pandas.read_parquet`` /
+    pyarrow / any parquet tool, independent of the pandas version, safe to load -- or pandas pickles (``fmt="pickle"``,
+    and the fallback when pyarrow is absent; stores written by earlier versions stay readable).  HDF5 / pytables, the
+    reference's container, is not a dependency of this backend (``export_hdf5`` converts when pytables is installed).
 
-    Append-only: every flush (``write_wave``) adds ONE new part file per table, ``<table>.w<k>.r<rank>.pkl``, and
+    Append-only: every flush (``write_wave``) adds ONE new part file per table, ``<table>.w<k>.r<rank>.<ext>``, and
     commits the wave by writing the marker ``_wave.w<k>.r<rank>.ok`` last (files are written to a temporary name and
     renamed, so a part is either complete or absent).  Parts without their marker -- a run killed mid-flush -- are
     ignored by readers and removed by the next run.  Nothing already written is ever re-read or re-written by an
     append (the reference's HDFStore.append, local_experts.py:526-548).  ``put`` writes a whole table
-    (``<table>.pkl``, the HDFStore.put(append=False) of the smoothing step)."""
+    (``<table>.<ext>``, the HDFStore.put(append=False) of the smoothing step)."""
 
-    def __init__(self, path: Optional[str], rank: int = 0):
+    def __init__(self, path: Optional[str], rank: int = 0, fmt: Optional[str] = None):
         self.path = path
         self.rank = int(rank)
+        if fmt is None:
+            fmt = "parquet" if _have_pyarrow() else "pickle"
+        if fmt not in ("parquet", "pickle"):
+            raise ValueError("fmt must be 'parquet' or 'pickle'")
+        if fmt == "parquet" and not _have_pyarrow():
+            raise ImportError("fmt='parquet' needs pyarrow")
+        self.fmt = fmt
+        self.ext = "parquet" if fmt == "parquet" else "pkl"
         if path:
             os.makedirs(path, exist_ok=True)
 
-    def _file(self, table):
-        return os.path.join(self.path, f"{table}.pkl")
+    def _whole(self, table):
+        """Path of the whole-table file of ``table`` (either format), or None."""
+        for ext in ("parquet", "pkl"):
+            f = os.path.join(self.path, f"{table}.{ext}")
+            if os.path.exists(f):
+                return f
+        return None
 
     def _scan(self):
         parts, marks = {}, set()
         for f in os.listdir(self.path):
+            if f.startswith(".tmp."):                       # unfinished temporary of some flush: never a table part
+                continue
             m = _MARK_RE.match(f)
             if m:
                 marks.add((int(m["k"]), int(m["r"])))
@@ -315,7 +356,8 @@ class ResultStore:
         return parts, marks
 
     def drop_uncommitted(self):
-        """Remove part files of this rank that no marker commits (left by a run that died during a flush)."""
+        """Remove part files of this rank that no marker commits (left by a run that died during a flush), and stale
+        temporaries of processes that no longer exist."""
         if not self.path:
             return
         parts, marks = self._scan()
@@ -323,10 +365,22 @@ class ResultStore:
             for k, r, f in plist:
                 if r == self.rank and (k, r) not in marks:
                     os.remove(os.path.join(self.path, f))
+        for f in os.listdir(self.path):
+            if f.startswith(".tmp."):
+                pid = f.split(".")[2]
+                alive = pid.isdigit() and os.path.exists(f"/proc/{pid}") and int(pid) != os.getpid()
+                if not alive:
+                    try:
+                        os.remove(os.path.join(self.path, f))
+                    except FileNotFoundError:
+                        pass
 
-    def _atomic_pickle(self, df, name):
+    def _atomic_write(self, df, name):
         tmp = os.path.join(self.path, f".tmp.{os.getpid()}.{name}")
-        df.to_pickle(tmp)
+        if name.endswith(".parquet"):
+            df.to_parquet(tmp, engine="pyarrow", index=True)
+        else:
+            df.to_pickle(tmp)
         os.replace(tmp, os.path.join(self.path, name))
 
     def write_wave(self, tables: Dict[str, pd.DataFrame]):
@@ -339,7 +393,7 @@ class ResultStore:
         _, marks = self._scan()
         k = 1 + max([kk for kk, r in marks if r == self.rank], default=0)
         for name, df in tables.items():
-            self._atomic_pickle(df, f"{name}.w{k:06d}.r{self.rank:03d}.pkl")
+            self._atomic_write(df, f"{name}.w{k:06d}.r{self.rank:03d}.{self.ext}")
         mark = os.path.join(self.path, f"_wave.w{k:06d}.r{self.rank:03d}.ok")
         with open(mark + ".tmp", "w") as f:
             f.write(json.dumps({"tables": sorted(tables), "rows": {n: int(len(d)) for n, d in tables.items()}}))
@@ -355,18 +409,22 @@ class ResultStore:
         parts, _ = self._scan()
         for _, _, f in parts.get(table, []):
             os.remove(os.path.join(self.path, f))
-        self._atomic_pickle(df, f"{table}.pkl")
+        old = self._whole(table)
+        self._atomic_write(df, f"{table}.{self.ext}")
+        if old is not None and not old.endswith("." + self.ext):
+            os.remove(old)
 
     def read(self, table) -> Optional[pd.DataFrame]:
         if not self.path:
             return None
         parts, marks = self._scan()
         pieces = []
-        if os.path.exists(self._file(table)):
-            pieces.append(pd.read_pickle(self._file(table)))
+        whole = self._whole(table)
+        if whole is not None:
+            pieces.append(_read_part(whole))
         for k, r, f in sorted(parts.get(table, [])):
             if (k, r) in marks:
-                pieces.append(pd.read_pickle(os.path.join(self.path, f)))
+                pieces.append(_read_part(os.path.join(self.path, f)))
         if not pieces:
             return None
         return pieces[0] if len(pieces) == 1 else pd.concat(pieces)
@@ -376,12 +434,52 @@ class ResultStore:
             return []
         parts, marks = self._scan()
         names = {t for t, pl in parts.items() if any((k, r) in marks for k, r, _ in pl)}
-        names |= {f[:-4] for f in os.listdir(self.path) if f.endswith(".pkl") and not _PART_RE.match(f)
-                  and not f.startswith(".tmp.")}
+        for f in os.listdir(self.path):
+            if f.startswith(".tmp.") or _PART_RE.match(f):
+                continue
+            m = _WHOLE_RE.match(f)
+            if m:
+                names.add(m["table"])
         return sorted(names)
 
     def tables(self) -> Dict[str, pd.DataFrame]:
         return {t: self.read(t) for t in self.table_names()}
+
+
+def export_parquet(store_path: str, out_dir: str, expert_order: bool = True) -> List[str]:
+    """ONE parquet file per table (``<out_dir>/<table>.parquet``, rows in expert order), from a store of either format:
+    what a consumer outside this package reads with ``pandas.read_parquet``.  Counterpart of handing the reference's
+    HDF5 results file to downstream tooling (``get_results_from_h5file``, GPSat/local_experts.py:1467-1620)."""
+    if not _have_pyarrow():
+        raise ImportError("export_parquet needs pyarrow")
+    os.makedirs(out_dir, exist_ok=True)
+    written = []
+    for name, df in get_results(store_path, expert_order=expert_order).items():
+        if df is None:
+            continue
+        f = os.path.join(out_dir, f"{name}.parquet")
+        df.to_parquet(f, engine="pyarrow", index=True)
+        written.append(f)
+    cfgs = [f for f in os.listdir(store_path) if f.startswith("oi_config") and f.endswith(".json")]
+    for f in cfgs:
+        with open(os.path.join(store_path, f)) as src, open(os.path.join(out_dir, f), "w") as dst:
+            dst.write(src.read())
+    return written
+
+
+def export_hdf5(store_path: str, h5_path: str, expert_order: bool = True):
+    """The store as ONE HDF5 file in the reference's layout (``pd.HDFStore`` tables keyed by table name, appendable
+    format with data columns), for GPSat's own readers (``get_results_from_h5file``, GPSat/local_experts.py:1467).  Needs
+    pytables, which is not a dependency of this backend: raises ImportError when it is absent (it is absent from the
+    build and GPU images, so this path has not been executed there)."""
+    try:
+        import tables  # noqa: F401
+    except Exception as e:                                   # pragma: no cover
+        raise ImportError("export_hdf5 needs pytables (pip install tables)") from e
+    with pd.HDFStore(h5_path, mode="w") as st:               # pragma: no cover
+        for name, df in get_results(store_path, expert_order=expert_order).items():
+            if df is not None and len(df):
+                st.put(name, df, format="table", data_columns=True)
 
 
 def get_results(store_path: str, expert_order: bool = False) -> Dict[str, pd.DataFrame]:
@@ -473,15 +571,15 @@ class BatchedLocalExpertOI:
                 constraints=self.constraints if rco is None else rco,
                 optim_kwargs=dict(model_config.get("replacement_optim_kwargs") or {}),
                 pred_kwargs=dict(model_config.get("replacement_pred_kwargs") or {}))
-        for pf in self.profiles.values():
-            if pf["pred_kwargs"].get("full_cov"):
-                raise NotImplementedError("full_cov=True tables are not written by the batched orchestrator "
-                                          "(use HipGPRModel.predict(full_cov=True) / Engine.fit_predict_batch(full_cov=True))")
         self.params_to_store = model_config.get("params_to_store") or PARAM_NAMES
         self.load_params = model_config.get("load_params")
-        if self.load_params is not None and self.load_params.get("previous", False):
-            raise NotImplementedError("load_params.previous=True is a serial cross-tile dependency "
-                                      "(local_experts.py:1200-1217) and is not defined for batched execution")
+        # load_params.previous (local_experts.py:1059-1064): start every tile from the running average of earlier optima
+        self.use_previous = bool(self.load_params is not None and self.load_params.get("previous", False))
+        if self.use_previous:
+            extra = set(self.load_params) - {"previous"}
+            if extra:
+                raise NotImplementedError(f"load_params.previous=True together with {sorted(extra)}")
+            self.load_params = None
         # ---- prediction locations (local_experts.py:254-264)
         plc = dict(pred_loc_config or {"method": "expert_loc"})
         self.pred_loc = PredictionLocations(coords_col=self.coords_col, **plc)
@@ -590,6 +688,13 @@ class BatchedLocalExpertOI:
         elif rank is None or world_size is None:
             rank, world_size = d_rank, d_world
         in_group = (not logical) and world_size > 1 and d_world == world_size
+        if world_size > 1 and not logical and not in_group:
+            # explicit rank / world_size without a process group of that size: the caller synchronises the ranks itself
+            # (nothing here can separate reading the resume state from rank 0's writes, and nothing can gather)
+            if gather:
+                raise RuntimeError(f"run(rank={rank}, world_size={world_size}, gather=True) needs an initialised "
+                                   f"torch.distributed group of {world_size} ranks (found {d_world}); pass gather=False to run "
+                                   f"this rank's shard on its own (start the ranks only after the store directory exists)")
         store = ResultStore(store_path, rank=rank)
         cc = self.coords_col
         D, H = len(cc), len(cc) + 2
@@ -668,7 +773,8 @@ class BatchedLocalExpertOI:
             pinfo[pi] = dict(kernel=kernel, max_iter=int(ok.get("max_iter", 10_000)),
                              eng_kw={k: ok[k] for k in ("max_ls", "ftol", "gtol", "adam_lr") if k in ok},
                              optimiser=ok.get("optimiser", "lbfgs") if optimise else "none",
-                             apply_scale=pf["pred_kwargs"].get("apply_scale", True))
+                             apply_scale=pf["pred_kwargs"].get("apply_scale", True),
+                             full_cov=bool(pf["pred_kwargs"].get("full_cov", False)) and predict)
         theta0 = np.zeros((len(ex), H))
         lo = np.full((len(ex), H), np.nan)
         hi = np.full((len(ex), H), np.nan)
@@ -705,6 +811,7 @@ class BatchedLocalExpertOI:
             for sl, tol in t_["clamp"]:
                 theta0[m_, sl] = clamp_within(theta0[m_, sl], t_["lo"][sl], t_["hi"][sl], tol)
         self.timings["params_s"] = time.perf_counter() - t0
+        want_cov = any(p_["full_cov"] for p_ in pinfo.values())
 
         # ---------------- shard: LPT on the cost model over the items of this run ----------------
         cost_n = np.where(kind == 2, n_obs, 0)
@@ -720,10 +827,12 @@ class BatchedLocalExpertOI:
         assert not np.isnan(obs_all).any(), "nans found in obs"
         self.timings.update(pack_wait_s=0.0, engine_s=0.0, tables_s=0.0, flush_s=0.0)
 
-        def tables_for(items, fixed, pred_cat):
+        def tables_for(items, fixed, pred_cat, cov_cat=None):
             return self._tables(ex[items], locs[items], kind[items], n_obs[items], fixed, pred_cat,
                                 [pcs[i] for i in items] if predict else None, save_params[items],
-                                [tmpl[p]["device"] for p in prof_id[items]], optimise, config_id, table_suffix)
+                                [tmpl[p]["device"] for p in prof_id[items]], optimise, config_id, table_suffix,
+                                cov_cat=cov_cat, cov_tiles=(kind[items] == 2) & np.array([pinfo[p]["full_cov"] for p in prof_id[items]], dtype=bool)
+                                if want_cov else None)
 
         # ---------------- pass 2: waves of one shard ----------------
         def pack_job(ids, pi):
@@ -757,7 +866,10 @@ class BatchedLocalExpertOI:
         # results do not depend on how tiles are batched (tests/test_gpu_parity.py::test_ragged_batch_tile_indexing_is_bit_exact).
         def run_shard(mine, shard_store):
             from concurrent.futures import ThreadPoolExecutor
-            fixed_rows, pred_rows = [], []
+            fixed_rows, pred_rows, cov_rows = [], [], []
+            # load_params.previous: the running average of earlier optima (rho = 0.95, local_experts.py:1200-1217); it starts
+            # from the default parameters of the first model built (:1053-1054)
+            prev = {"theta": None}
             jobs = []                                                  # (wave index, profile, positions within the wave)
             waves = [mine[w0:w0 + wave_n] for w0 in range(0, len(mine), wave_n)]
             for wi, items in enumerate(waves):
@@ -771,20 +883,23 @@ class BatchedLocalExpertOI:
             def open_wave(wi):
                 items = waves[wi]
                 state[wi] = (np.full((len(items), H + 6), np.nan),       # theta, nll, status, n_eval, n_iter, seconds, obs mean
-                             [np.zeros((0, 3))] * len(items))
+                             [np.zeros((0, 3))] * len(items), [np.zeros((0, 2))] * len(items))
 
             def close_wave(wi):
                 items = waves[wi]
-                fixed, preds = state.pop(wi)
+                fixed, preds, covs = state.pop(wi)
                 tt = time.perf_counter()
                 pred_cat = np.concatenate(preds) if len(preds) else np.zeros((0, 3))
-                tables = tables_for(items, fixed, pred_cat)
+                cov_cat = (np.concatenate(covs) if len(covs) else np.zeros((0, 2))) if want_cov else None
+                tables = tables_for(items, fixed, pred_cat, cov_cat)
                 self.timings["tables_s"] += time.perf_counter() - tt
                 tf = time.perf_counter()
                 shard_store.write_wave(tables)                        # commit: these experts are done
                 self.timings["flush_s"] += time.perf_counter() - tf
                 fixed_rows.append(fixed)
                 pred_rows.append(pred_cat)
+                if want_cov:
+                    cov_rows.append(cov_cat)
 
             with ThreadPoolExecutor(max_workers=1) as pool:
                 nxt = pool.submit(pack_job, waves[jobs[0][0]][jobs[0][2]], jobs[0][1]) if jobs else None
@@ -797,7 +912,7 @@ class BatchedLocalExpertOI:
                         done_waves += 1
                     if wi not in state:
                         open_wave(wi)
-                    fixed, preds = state[wi]
+                    fixed, preds, covs = state[wi]
                     ids = waves[wi][loc_ids]
                     te = time.perf_counter()
                     pk = nxt.result()
@@ -805,12 +920,24 @@ class BatchedLocalExpertOI:
                     if k + 1 < len(jobs):
                         nxt = pool.submit(pack_job, waves[jobs[k + 1][0]][jobs[k + 1][2]], jobs[k + 1][1])
                     t_, p_ = tmpl[pi], pinfo[pi]
+                    th_call = theta0[ids]
+                    if self.use_previous:
+                        if prev["theta"] is None:
+                            prev["theta"] = t_["theta_default"].copy()
+                        th_call = np.tile(prev["theta"], (len(ids), 1))
+                        for sl, tol in t_["clamp"]:                   # set_parameters(prev), then the constraints' clamp
+                            th_call[:, sl] = clamp_within(th_call[:, sl], t_["lo"][sl], t_["hi"][sl], tol)
                     te = time.perf_counter()
                     r = self.engine.fit_predict_batch(D=D, obs_off=pk["o_off"], X=pk["X"], y=pk["y"], pred_off=pk["p_off"],
-                                                      Xs=pk["Xs"], theta0=theta0[ids], lo=lo[ids], hi=hi[ids],
+                                                      Xs=pk["Xs"], theta0=th_call, lo=lo[ids], hi=hi[ids],
                                                       trainable=t_["trainable"], kernel=p_["kernel"],
                                                       optimiser=p_["optimiser"], max_iter=p_["max_iter"],
-                                                      dtype=self.dtype, **p_["eng_kw"])
+                                                      dtype=self.dtype, **p_["eng_kw"],
+                                                      **({"full_cov": True} if p_["full_cov"] else {}))
+                    if self.use_previous and p_["optimiser"] != "none":
+                        for kk in range(len(ids)):                    # expert order; only successful optimisations, no NaN
+                            if r.status[kk] == 0 and save_params[ids[kk]] and not np.isnan(r.theta[kk]).any():
+                                prev["theta"] = 0.95 * prev["theta"] + 0.05 * r.theta[kk]
                     dt = (time.perf_counter() - te) / len(ids)
                     self.timings["engine_s"] += time.perf_counter() - te
                     fixed[loc_ids, :H] = r.theta
@@ -826,6 +953,15 @@ class BatchedLocalExpertOI:
                         p_off = pk["p_off"]
                         for kk, j in enumerate(loc_ids):
                             preds[j] = pr[p_off[kk]:p_off[kk + 1]]
+                        if p_["full_cov"]:
+                            fc = np.asarray(r.f_cov, dtype=np.float64)
+                            for kk, j in enumerate(loc_ids):
+                                P_ = int(p_off[kk + 1] - p_off[kk])
+                                fcov = fc[r.cov_off[kk]:r.cov_off[kk + 1]].reshape(P_, P_)
+                                ycov = fcov.copy()                     # y_cov = f*_cov + diag(y_var - f*_var), gpflow_models.py:250-254
+                                seg = pr[p_off[kk]:p_off[kk + 1]]
+                                ycov[np.arange(P_), np.arange(P_)] += seg[:, 2] - seg[:, 1]
+                                covs[j] = np.stack([fcov.reshape(-1), ycov.reshape(-1)], axis=1)
                     if last_job_of_wave[wi] == k:
                         close_wave(wi)
                         done_waves = wi + 1
@@ -837,7 +973,8 @@ class BatchedLocalExpertOI:
             fixed_all = np.concatenate(fixed_rows) if fixed_rows else np.zeros((0, H + 6))
             preds_all = np.concatenate(pred_rows) if pred_rows else np.zeros((0, 3))
             cnt = np.where(kind[mine] == 2, n_pred[mine] if predict else 0, 0).astype(np.int64)
-            return fixed_all, preds_all, cnt, mine
+            cov_all = (np.concatenate(cov_rows) if cov_rows else np.zeros((0, 2))) if want_cov else None
+            return fixed_all, preds_all, cnt, mine, cov_all
 
         all_items = np.nonzero(kind != 0)[0]
         if logical:
@@ -847,27 +984,35 @@ class BatchedLocalExpertOI:
                 st_r = ResultStore(store_path, rank=r_)
                 st_r.drop_uncommitted()
                 shards.append(run_shard(parts[r_], st_r))
-            fixed_g, preds_g, _ = sharding.assemble_global(shards, len(ex))
-            out = tables_for(all_items, fixed_g[all_items], preds_g)
+            fixed_g, preds_g, _ = sharding.assemble_global([sh[:4] for sh in shards], len(ex))
+            cov_g = None
+            if want_cov:
+                cc2 = [np.where(np.array([pinfo[p]["full_cov"] for p in prof_id[sh[3]]], dtype=bool), sh[2] ** 2, 0) for sh in shards]
+                cov_g = sharding.assemble_global([(sh[0], sh[4], c2, sh[3]) for sh, c2 in zip(shards, cc2)], len(ex))[1]
+            out = tables_for(all_items, fixed_g[all_items], preds_g, cov_g)
         else:
             mine = parts[rank] if world_size > 1 else parts[0]
-            fixed_all, preds_all, cnt, _ = run_shard(mine, store)
+            fixed_all, preds_all, cnt, _, cov_all = run_shard(mine, store)
             out = None
             if world_size > 1 and gather:
                 # ONE exchange of per-tile results (RCCL over xGMI on the GPU node); tables in expert order on rank 0
-                got = sharding.gather_arrays(fixed_all, preds_all, cnt, mine, len(ex), world_size, rank,
-                                             getattr(self.engine, "device_id", None))
+                dev_id = getattr(self.engine, "device_id", None)
+                got = sharding.gather_arrays(fixed_all, preds_all, cnt, mine, len(ex), world_size, rank, dev_id)
+                got_c = None
+                if want_cov:                                         # the P x P blocks travel the same way (counts P^2)
+                    c2 = np.where(np.array([pinfo[p]["full_cov"] for p in prof_id[mine]], dtype=bool), cnt ** 2, 0)
+                    got_c = sharding.gather_arrays(fixed_all, cov_all, c2, mine, len(ex), world_size, rank, dev_id)
                 if rank == 0:
                     fixed_g, preds_g, _ = got
-                    out = tables_for(all_items, fixed_g[all_items], preds_g)
+                    out = tables_for(all_items, fixed_g[all_items], preds_g, got_c[1] if got_c is not None else None)
             if out is None:
-                out = tables_for(mine, fixed_all, preds_all)
+                out = tables_for(mine, fixed_all, preds_all, cov_all)
         self.run_seconds = time.perf_counter() - t_start
         return out
 
     # ------------------------------------------------------------------------------------------------------
     def _tables(self, ex_ids, locs, kind, n_obs, fixed, pred_cat, pcs, save_params, devices, optimise, config_id,
-                table_suffix):
+                table_suffix, cov_cat=None, cov_tiles=None):
         """Reference-layout tables for a run of items (rows of ``fixed`` align with the items, ``pred_cat`` holds the
         predictions of the tiles among them back to back).  Pure array assembly (GPSat/local_experts.py:691-747)."""
         cc = self.coords_col
@@ -902,6 +1047,16 @@ class BatchedLocalExpertOI:
             for ci, c_ in enumerate(cc):
                 pr[f"pred_loc_{c_}"] = raw[:, ci]
             out["preds"] = pd.DataFrame(pr, index=_index_for(cc, np.repeat(locs, cnt, axis=0)))
+            if cov_cat is not None:
+                # 2-D arrays of the prediction dict -> table "preds_2" with _dim_0, _dim_1 (row-major), local_experts.py:735-745
+                c2 = np.where(cov_tiles, cnt, 0)
+                tot2 = int((c2 * c2).sum())
+                assert tot2 == len(cov_cat), (tot2, len(cov_cat))
+                if tot2:
+                    d0 = np.concatenate([np.repeat(np.arange(c), c) for c in c2 if c])
+                    d1 = np.concatenate([np.tile(np.arange(c), c) for c in c2 if c])
+                    out["preds_2"] = pd.DataFrame({"_dim_0": d0, "_dim_1": d1, "f*_cov": cov_cat[:, 0], "y_cov": cov_cat[:, 1]},
+                                                  index=_index_for(cc, np.repeat(locs, c2 * c2, axis=0)))
         else:
             out["preds"] = pd.DataFrame()
         return {f"{k}{table_suffix}": v for k, v in out.items()}

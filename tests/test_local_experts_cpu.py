@@ -41,9 +41,20 @@ class OracleEngine:
                                  Xs.astype(np.float64), theta0, lo, hi, np.asarray(trainable, bool), max_iter=max_iter,
                                  optimise=optimiser != "none")
         T = len(obs_off) - 1
+        fc = cov_off = None
+        if kw.get("full_cov"):
+            Pt = np.diff(pred_off)
+            cov_off = np.concatenate([[0], np.cumsum(Pt * Pt)]).astype(np.int64)
+            fc = np.zeros(int(cov_off[-1]))
+            for t in range(T):
+                a, b, pa, pb = obs_off[t], obs_off[t + 1], pred_off[t], pred_off[t + 1]
+                if pb > pa:
+                    fcov, _ = go.predict_cov(go.KERNEL_IDS[kernel], X[a:b].astype(np.float64), y[a:b].astype(np.float64),
+                                             Xs[pa:pb].astype(np.float64), o["theta"][t])
+                    fc[cov_off[t]:cov_off[t + 1]] = fcov.reshape(-1)
         return BatchResult(theta=o["theta"], nll=o["nll"], status=np.where(o["success"], 0, 1).astype(np.int32),
                            n_eval=o["n_eval"].astype(np.int32), f_mean=o["f_mean"].astype(np.float32),
-                           f_var=o["f_var"].astype(np.float32), y_var=o["y_var"].astype(np.float32))
+                           f_var=o["f_var"].astype(np.float32), y_var=o["y_var"].astype(np.float32), f_cov=fc, cov_off=cov_off)
 
 
 @pytest.mark.parametrize("radius,locs,nobs,npred,ls", [

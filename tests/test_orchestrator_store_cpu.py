@@ -183,3 +183,112 @@ def test_logical_shards_in_one_process(tmp_path):
     _assert_same_tables(ref, got)
     assert {f.split(".")[2] for f in os.listdir(store) if f.startswith("run_details.w")} == {"r000", "r001", "r002"}
     _assert_same_tables(ref, {k: v for k, v in get_results(store, expert_order=True).items() if k in ref})
+
+
+def test_store_is_parquet_and_reads_older_pickle_stores(tmp_path):
+    """Default container: Apache Parquet parts (any parquet reader, no pandas-version binding, nothing executed on load);
+    a store written as pandas pickles stays readable; an unfinished temporary is never taken for a table part."""
+    import pyarrow.parquet as pq
+    from gpsat_amd.local_experts import ResultStore, export_parquet
+    cfg = _grid_case(9)
+    store = str(tmp_path / "pq")
+    full = BatchedLocalExpertOI(engine=OracleEngine(), **cfg).run(store_path=store, store_every=4)
+    files = os.listdir(store)
+    assert any(f.startswith("preds.w000001.r000.") and f.endswith(".parquet") for f in files)
+    assert not any(f.endswith(".pkl") for f in files)
+    t = pq.read_table(os.path.join(store, "preds.w000001.r000.parquet"))            # readable without this package
+    assert {"f*", "f*_var", "y_var", "f_bar", "_dim_0", "pred_loc_x"} <= set(t.column_names)
+    _assert_same_tables(full, {k: v for k, v in get_results(store).items() if k in full}, ignore=())
+    # the same run into a pickle store: identical tables
+    st2 = str(tmp_path / "pk")
+    os.makedirs(st2)
+    rs = ResultStore(st2, fmt="pickle")
+    for k, v in full.items():
+        rs.append(k, v)
+    _assert_same_tables(full, {k: v for k, v in get_results(st2).items() if k in full}, ignore=())
+    # a truncated temporary left by a crash (ADVICE r2): ignored by readers even when a marker for its wave exists,
+    # removed by the next drop_uncommitted
+    tmpf = os.path.join(store, ".tmp.999999999.preds.w000001.r000.parquet")
+    open(tmpf, "wb").write(b"trunc")
+    assert ".tmp.999999999.preds" not in get_results(store) and set(ResultStore(store).table_names()) >= set(full)
+    ResultStore(store).drop_uncommitted()
+    assert not os.path.exists(tmpf)
+    out = export_parquet(store, str(tmp_path / "export"))
+    got = {os.path.basename(f)[:-8]: pd.read_parquet(f) for f in out}
+    _assert_same_tables(full, {k: v for k, v in got.items() if k in full}, ignore=())
+    assert os.path.exists(tmp_path / "export" / "oi_config.json")
+
+
+def test_full_cov_tables(tmp_path):
+    """pred_kwargs.full_cov=True: table preds_2 with _dim_0, _dim_1, f*_cov, y_cov in the layout
+    dict_of_array_to_table(concat=True, table="preds") gives 2-D arrays (GPSat/local_experts.py:691-747,
+    GPSat/models/gpflow_models.py:245-263); values against the oracle's predict_cov."""
+    cfg = _grid_case(4)
+    cfg["model_config"]["pred_kwargs"] = {"full_cov": True}
+    eng = OracleEngine()
+    tabs = BatchedLocalExpertOI(engine=eng, **cfg).run(store_path=str(tmp_path / "cov"), store_every=3)
+    p1, p2 = tabs["preds"], tabs["preds_2"]
+    assert list(p2.columns) == ["_dim_0", "_dim_1", "f*_cov", "y_cov"] and p2.index.names == ["x", "y", "t"]
+    P = 6                                                                       # 3 x 2 shifted prediction locations
+    assert len(p1) == 4 * P and len(p2) == 4 * P * P
+    for loc, grp in p2.groupby(level=[0, 1, 2], sort=False):
+        assert grp["_dim_0"].tolist() == np.repeat(np.arange(P), P).tolist()
+        assert grp["_dim_1"].tolist() == np.tile(np.arange(P), P).tolist()
+        fc = grp["f*_cov"].values.reshape(P, P)
+        yc = grp["y_cov"].values.reshape(P, P)
+        one = p1.loc[loc]
+        np.testing.assert_allclose(np.diag(fc), one["f*_var"].values, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(np.diag(yc), one["y_var"].values, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(yc - np.diag(np.diag(yc)), fc - np.diag(np.diag(fc)), rtol=0, atol=0)
+        np.testing.assert_allclose(fc, fc.T, rtol=1e-12, atol=1e-14)
+    disk = get_results(str(tmp_path / "cov"), expert_order=True)
+    _assert_same_tables(tabs, {k: v for k, v in disk.items() if k in tabs})
+    # logical shards return the same preds_2
+    got = BatchedLocalExpertOI(engine=OracleEngine(), **cfg).run(world_size=2)
+    _assert_same_tables(tabs, got)
+
+
+def test_load_params_previous_is_the_serial_recurrence_at_chunk_1():
+    """load_params.previous=True (GPSat/local_experts.py:1059-1064,1200-1217): every tile starts from the running average
+    (rho 0.95) of the optima of the successfully optimised tiles before it.  engine_chunk=1 is the reference's serial
+    recurrence; a larger chunk lags the average by one call."""
+    cfg = _grid_case(9)
+    cfg["model_config"]["load_params"] = {"previous": True}
+    cfg["model_config"]["optim_kwargs"] = {"max_iter": 500}                     # run to convergence: optimise_success
+    eng = OracleEngine()
+    seen = []
+    orig = eng.fit_predict_batch
+
+    def spy(**kw):
+        seen.append(np.array(kw["theta0"]))
+        return orig(**kw)
+    eng.fit_predict_batch = spy
+    tabs = BatchedLocalExpertOI(engine=eng, **cfg).run(engine_chunk=1)
+    assert len(seen) == 9 and all(len(s_) == 1 for s_ in seen)
+    ls = tabs["lengthscales"]["lengthscales"].values.reshape(9, 3)
+    kv = tabs["kernel_variance"]["kernel_variance"].values
+    lv = tabs["likelihood_variance"]["likelihood_variance"].values
+    ok = tabs["run_details"]["optimise_success"].values
+    prev = np.array([1.0, 1.0, 1.0, 1.0, 1.0])                                  # defaults of the first model
+    for t in range(9):
+        start = prev.copy()
+        start[:3] = np.clip(start[:3], 1e-8 / np.array([0.5, 0.5, 2.0]) + 1e-2, np.array([2.0, 2.0, 4.0]) / np.array([0.5, 0.5, 2.0]) - 1e-2)
+        np.testing.assert_allclose(seen[t][0], start, rtol=1e-13)
+        if ok[t]:
+            prev = 0.95 * prev + 0.05 * np.concatenate([ls[t], [kv[t], lv[t]]])
+    assert ok.any()
+    # chunk of 4: the tiles of one call share the start of the call
+    seen.clear()
+    BatchedLocalExpertOI(engine=eng, **cfg).run(engine_chunk=4)
+    assert [len(s_) for s_ in seen] == [4, 4, 1]
+    assert (seen[0] == seen[0][0]).all() and (seen[1] == seen[1][0]).all() and not np.allclose(seen[0][0], seen[1][0])
+
+
+def test_explicit_rank_without_group_is_refused_up_front():
+    cfg = _grid_case(4)
+    eng = OracleEngine()
+    with pytest.raises(RuntimeError, match="needs an initialised"):
+        BatchedLocalExpertOI(engine=eng, **cfg).run(rank=1, world_size=2)
+    assert eng.calls == []                                                      # refused before any work
+    part = BatchedLocalExpertOI(engine=eng, **cfg).run(rank=1, world_size=2, gather=False)
+    assert 0 < len(part["run_details"]) < 4
