@@ -179,7 +179,7 @@ def test_unsupported_configs_fail_loudly():
     df, X_grid, noise_std = _notebook_data()
     base = _configs(df, X_grid, 0.1, [0.2], noise_std)
     bad = dict(base)
-    bad["model_config"] = {**base["model_config"], "load_params": {"previous": True}}
+    bad["model_config"] = {**base["model_config"], "load_params": {"previous": True, "file": "somewhere"}}
     with pytest.raises(NotImplementedError):
         BatchedLocalExpertOI(engine=OracleEngine(), **bad)
     bad = dict(base)
