@@ -676,7 +676,8 @@ class BatchedLocalExpertOI:
         ``max_tiles_per_call`` is the older name of the same knob).  ``engine_chunk``: tiles per engine call inside a wave
         (default 2048): while the GPU works on one call the host packs the next (gather, scale, de-mean, centre, cast).  ``rank`` / ``world_size``: tile-sharded run, one
         process per GPU (default: taken from an initialised ``torch.distributed`` group, else 0 / 1); with
-        ``gather=True`` rank 0 returns the global tables in expert order, the other ranks their own shard's.
+        ``gather=True`` rank 0 returns the global tables in expert order, the other ranks their own shard's
+        (``gather="always"`` runs the exchange in a group of one rank too).
         ``world_size > 1`` with ``rank=None`` and no process group runs all the LOGICAL shards one after the other on
         this process's engine and merges them with the routine that closes the gather -- the one-GPU rehearsal of the
         multi-GPU path."""
@@ -994,8 +995,9 @@ class BatchedLocalExpertOI:
             mine = parts[rank] if world_size > 1 else parts[0]
             fixed_all, preds_all, cnt, _, cov_all = run_shard(mine, store)
             out = None
-            if world_size > 1 and gather:
+            if gather and (world_size > 1 or (gather == "always" and d_world == 1 and _dist_initialised())):
                 # ONE exchange of per-tile results (RCCL over xGMI on the GPU node); tables in expert order on rank 0
+                # (gather="always": also in a group of ONE rank -- the one-GPU rehearsal of the exchange on RCCL)
                 dev_id = getattr(self.engine, "device_id", None)
                 got = sharding.gather_arrays(fixed_all, preds_all, cnt, mine, len(ex), world_size, rank, dev_id)
                 got_c = None
@@ -1060,6 +1062,14 @@ class BatchedLocalExpertOI:
         else:
             out["preds"] = pd.DataFrame()
         return {f"{k}{table_suffix}": v for k, v in out.items()}
+
+
+def _dist_initialised():
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
+    except Exception:
+        return False
 
 
 def _dist_rank_world():
