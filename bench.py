@@ -71,6 +71,23 @@ def measured_traffic(key, sig):
         return None, None
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup's CPU quota (cpu.max).  The GPU box gives
+    one GPU's share of the host: 256 hardware threads visible, a quota of 16 CPUs -- more processes than that only
+    time-share the quota (measured: 128 processes 18 tiles/s against 41.7 with 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -280,10 +297,7 @@ def cpu_baseline(w, a, workers):
                                                layout=f"{workers} single-threaded processes, SciPy default convergence (maxiter 10000)")
     # every core this process may run on (the GPU box gives one GPU's share of the host; the judge asked for the all-core
     # figure beside the 16-process one) and the scikit-learn line of BASELINE.md section 2
-    try:
-        ncore = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncore = os.cpu_count() or workers
+    ncore = usable_cpus()
     big = min(ncore, 128)
     if big > workers and not a.exact_iters:
         with get_context("fork").Pool(big) as pool:
@@ -293,8 +307,8 @@ def cpu_baseline(w, a, workers):
             wall_a = time.perf_counter() - t0
         modes["budget_all_cores"] = dict(tiles_per_s=round(len(res_a) / wall_a, 3), tiles=len(res_a), wall_s=round(wall_a, 2),
                                          evals_per_tile=round(float(np.mean([r[1] for r in res_a])), 2),
-                                         layout=f"{big} single-threaded processes ({ncore} hardware threads usable by this process, "
-                                                f"{os.cpu_count()} on the host)")
+                                         layout=f"{big} single-threaded processes ({ncore} CPUs usable by this process, "
+                                                f"{os.cpu_count()} hardware threads on the host)")
     if optimise and not a.exact_iters and not a.no_sklearn:
         with get_context("fork").Pool(workers) as pool:
             pool.map(_cpu_warm, range(workers * 2))
@@ -320,7 +334,7 @@ def cpu_baseline(w, a, workers):
         else "objective + predict only"
     cpu_nll = {"tiles": n_done, "nll": [r[3] for r in res]}        # objective reached within the iteration budget, per tile
     return {"value": m["tiles_per_s"], "unit": "tiles/s", "cores": cores_of[best],
-            "kind": "port", "cpu_model": cpu_model(), "host_threads": os.cpu_count(),
+            "kind": "port", "cpu_model": cpu_model(), "host_threads": os.cpu_count(), "usable_cpus": usable_cpus(),
             "sample": f"{m['tiles']} of the same tiles, fp64 NumPy/SciPy oracle ({what}, {m['evals_per_tile']} evals/tile, "
                       f"predict P={P}), {m['layout']}, {m['wall_s']} s wall (pool start-up excluded); fastest of the layouts in `modes`",
             "modes": modes, "_nll": cpu_nll}
@@ -370,7 +384,7 @@ def main():
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     ncpu = os.cpu_count() or 1
-    workers = a.workers if a.workers > 0 else max(1, min(16, ncpu // max(1, min(world, 8))))
+    workers = a.workers if a.workers > 0 else max(1, min(16, usable_cpus(), ncpu // max(1, min(world, 8))))
 
     # ---- host-side work that forks worker processes happens BEFORE the GPU / RCCL are initialised
     w = build_workload(a, rank, world, workers)
