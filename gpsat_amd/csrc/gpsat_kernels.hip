@@ -97,16 +97,33 @@ __device__ __forceinline__ f32x16 pack16(const f32x4& a, const f32x4& b, const f
 }
 
 // global block `blk` of the workgroup's workspace
+#ifndef GPSAT_LD_AUX
+#define GPSAT_LD_AUX 16          // cache policy of workspace block loads  (16 = sc1, 0 = default, 2 = nt)
+#endif
+#ifndef GPSAT_ST_AUX
+#define GPSAT_ST_AUX 16          // ... and stores
+#endif
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// Workspace blocks move as buffer_load / buffer_store_dwordx4 with the block index in the scalar offset.
 __device__ __forceinline__ f32x16 ldg(const float* __restrict__ ws, int blk, int lane) {
-    const f32x4* q = reinterpret_cast<const f32x4*>(ws + (size_t)blk * BLK) + lane;
-    return pack16(q[0], q[64], q[128], q[192]);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws), 0, 0x7fffffff, 0x00020000);
+    const int so = blk * (BLK * 4), vo = lane * 16;
+    const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, GPSAT_LD_AUX));
+    const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vo + 1024, so, GPSAT_LD_AUX));
+    const f32x4 c = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vo + 2048, so, GPSAT_LD_AUX));
+    const f32x4 d = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vo + 3072, so, GPSAT_LD_AUX));
+    return pack16(a, b, c, d);
 }
 
 __device__ __forceinline__ void stg(float* __restrict__ ws, int blk, int lane, const f32x16& v) {
-    f32x4* q = reinterpret_cast<f32x4*>(ws + (size_t)blk * BLK) + lane;
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(ws, 0, 0x7fffffff, 0x00020000);
+    const int so = blk * (BLK * 4), vo = lane * 16;
     f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
     f32x4 c = {v[8], v[9], v[10], v[11]}, d = {v[12], v[13], v[14], v[15]};
-    q[0] = a; q[64] = b; q[128] = c; q[192] = d;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), r, vo, so, GPSAT_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, b), r, vo + 1024, so, GPSAT_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, c), r, vo + 2048, so, GPSAT_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d), r, vo + 3072, so, GPSAT_ST_AUX);
 }
 
 // LDS block at float offset `off` (16-byte aligned)
