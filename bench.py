@@ -161,15 +161,17 @@ def build_workload(a, rank, world, workers):
         kid = 2
         sizes = [128, 256, 384, 512, 768, 1024, 1536, 2048]
         Ns = np.random.default_rng(rank).choice(sizes, T)
-        protos = gen_tiles([(100 + 10 * i + j, n, P, D, kid) for i, n in enumerate(sizes) for j in range(2)], workers)
-        proto = {n: protos[2 * i:2 * i + 2] for i, n in enumerate(sizes)}
-        parts = [proto[int(n)][t % 2] for t, n in enumerate(Ns)]
+        NPR = 8                          # prototype tiles per size class (r2: two -- 16 optimiser trajectories in all made
+        #                                  evaluations per tile jump by 15 % with any change of rounding)
+        protos = gen_tiles([(100 + 10 * i + j, n, P, D, kid) for i, n in enumerate(sizes) for j in range(NPR)], workers)
+        proto = {n: protos[NPR * i:NPR * i + NPR] for i, n in enumerate(sizes)}
+        parts = [proto[int(n)][t % NPR] for t, n in enumerate(Ns)]
         lo, hi = syn.default_bounds(T, D)
         w.update(name="BASELINE.json configs[2]: ragged tiles N in {128..2048}, Matern-3/2, 3D inputs, fp32", key="configs2",
                  T=T, Ns=Ns, kid=kid, kernel="Matern32", optimiser="lbfgs", max_iter=a.max_iter,
                  X=np.concatenate([p[0] for p in parts]).astype(np.float32), y=np.concatenate([p[1] for p in parts]).astype(np.float32),
                  Xs=np.concatenate([p[2] for p in parts]).astype(np.float32), theta0=np.ones((T, D + 2)), lo=lo, hi=hi,
-                 data="synthetic (two prototype tiles per size class, replicated)")
+                 data="synthetic (eight prototype tiles per size class, replicated)")
     else:
         T = a.tiles if a.tiles != 4096 else 1024
         kid = 0

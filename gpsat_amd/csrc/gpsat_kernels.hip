@@ -226,6 +226,7 @@ struct Ctx {
     Lay L;
     float* ws;                   // this workgroup's global workspace
     int zb, dT0, vs0, cv0;       // block indices: zero block, DinvT[0], V scratch, V of all chunks (full covariance)
+    int gp0;                     // byte offset of the gradient phase's per-group partial sums (aliases the V scratch)
     int N, NB, Npad, P;
     int tid, lane, w, h, g;
     float sf2, sn2;
@@ -612,8 +613,11 @@ __device__ __forceinline__ void pt_group_kloop(const Ctx<D, KN>& c, const Panel<
 
 // row r of a group: X = L_jr^-1 W_r, store, alpha update; r = 0 also folds row j0 into the row-j1 RHS.
 // `par` selects the LDS copy of the panel's factors (double-buffered across panels, see phase_pt).
+// apsum[n]: item n's contribution to alpha (M-type items), summed over the panel's rows and added to alpha ONCE after the
+// last row -- one read-modify-write per group and column, whoever runs the group.
 template <int D, int KN>
-__device__ __forceinline__ void pt_group_row(const Ctx<D, KN>& c, const Panel<D>& p, int g, int r, int par, f32x16 (&W)[4]) {
+__device__ __forceinline__ void pt_group_row(const Ctx<D, KN>& c, const Panel<D>& p, int g, int r, int par, f32x16 (&W)[4],
+                                             float (&apsum)[2]) {
     const int NB = c.NB, lane = c.lane;
     const int jr = p.j0 + r;
     const f32x16 Lop = ldl(c.L.LT + (2 * par + r) * BLK, lane);
@@ -636,7 +640,8 @@ __device__ __forceinline__ void pt_group_row(const Ctx<D, KN>& c, const Panel<D>
 #pragma unroll
                 for (int q = 0; q < 16; ++q) ap = fmaf(X[q], lds_f[c.L.z + 32 * jr + rho(q, c.h)], ap);
                 ap = xhalf_sum(ap);
-                if (c.h == 0) lds_f[c.L.alpha + 32 * col + c.g] += ap;
+                apsum[n] = (r == 0) ? ap : apsum[n] + ap;
+                if (r == p.has1 && c.h == 0) lds_f[c.L.alpha + 32 * col + c.g] += apsum[n];
             }
             if (fold) {
                 f32x16 T = zero16();
@@ -918,8 +923,9 @@ __device__ __forceinline__ bool pt_run_group(const Ctx<D, KN>& c, const Panel<D>
     if (!pt_wait(sh, &sh->ready, sq + 1)) return false;
     PROF_END(c, 3);
     TRACE(c, 24, sq * 16 + g);
-    pt_group_row<D, KN>(c, q, g, 0, sq & 1, W);
-    if (q.has1) pt_group_row<D, KN>(c, q, g, 1, sq & 1, W);
+    float apsum[2] = {0.f, 0.f};
+    pt_group_row<D, KN>(c, q, g, 0, sq & 1, W, apsum);
+    if (q.has1) pt_group_row<D, KN>(c, q, g, 1, sq & 1, W, apsum);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (c.lane == 0) {
 #pragma unroll
@@ -1026,84 +1032,124 @@ __device__ __forceinline__ void phase_pt(Ctx<D, KN>& c, const bool want_m) {
 // phase G: (K^-1)_ab = sum_{c>=a} M_ca^T M_cb for a >= b, by groups of 2 block rows x 2 block columns
 // per wave (4 accumulators, double-buffered operand registers), contracted in registers against
 // dK/dtheta recomputed on the fly (K^-1 is never stored).  Writes sh->gth (dNLL/dtheta).
+// Groups are pulled from ONE queue, largest first (group index = ia (ia + 1) / 2 + ib for the block-row pair ia and the
+// block-column pair ib <= ia; its k-loop has NB - 2 ia steps).  Every group leaves its D + 2 partial sums PER LANE in the
+// workspace (gpart, aliasing the prediction scratch, which is idle during an evaluation); they are then added up in a
+// fixed order -- the gradient does not depend on which wave ran which group (bit for bit), so the queue may be dynamic.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void st_part(float* __restrict__ ws, int byte_off, int lane, float v) {
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(ws, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, lane * 4, byte_off, GPSAT_ST_AUX);
+}
+
+__device__ __forceinline__ float ld_part(const float* __restrict__ ws, int byte_off, int lane) {
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws), 0, 0x7fffffff, 0x00020000);
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, byte_off, GPSAT_LD_AUX));
+}
+
+// one K^-1 group (a0 = 2 ia, b0 = 2 ib): k-loop, contraction, per-lane partial sums -> gpart[g]
 template <int D, int KN>
-__device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
-    Shared* sh = shared_state();
+__device__ __forceinline__ void grad_group(const Ctx<D, KN>& c, int g, int ia, int ib) {
     const int NB = c.NB, lane = c.lane;
+    const int a0 = 2 * ia, b0 = 2 * ib;
+    const int a1 = a0 + 1;
+    const bool hasa1 = a1 < NB;
+    const int bmax = hasa1 ? a1 : a0;
+    PROF_BEGIN();
+    const int b1 = b0 + 1;
+    const bool hasb1 = b1 <= bmax;
+    TRACE(c, 70, a0);
+    const bool use01 = hasb1 && b1 <= a0;      // (a0, b1) is a lower block (false on the diagonal group)
+    f32x16 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = zero16();
+    // M_cc,x lives at block cc*NB + x (cc >= x).  First step cc = a0: only row a0 exists (M_a0,a1 = 0)
+    f32x16 A0 = ldg(c.ws, a0 * NB + a0, lane);
+    f32x16 B0 = ldg(c.ws, a0 * NB + b0, lane);
+    f32x16 B1 = ldg(c.ws, use01 ? a0 * NB + b1 : c.zb, lane);
+    f32x16 A1 = A0;
+    if (a0 + 1 < NB) {
+        f32x16 nA0 = ldg(c.ws, a1 * NB + a0, lane);
+        f32x16 nA1 = ldg(c.ws, a1 * NB + a1, lane);
+        f32x16 nB0 = ldg(c.ws, a1 * NB + b0, lane);
+        f32x16 nB1 = ldg(c.ws, hasb1 ? a1 * NB + b1 : c.zb, lane);
+        mma_blk(acc[0], A0, B0);
+        if (use01) mma_blk(acc[1], A0, B1);
+        A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
+        for (int cc = a1; cc + 1 < NB; ++cc) {          // last step peeled, as in pt_group_kloop
+            const int cn = cc + 1;
+            nA0 = ldg(c.ws, cn * NB + a0, lane);
+            nA1 = ldg(c.ws, cn * NB + a1, lane);
+            nB0 = ldg(c.ws, cn * NB + b0, lane);
+            nB1 = ldg(c.ws, hasb1 ? cn * NB + b1 : c.zb, lane);
+            mma_blk(acc[0], A0, B0);
+            if (use01) mma_blk(acc[1], A0, B1);
+            mma_blk(acc[2], A1, B0);
+            if (hasb1) mma_blk(acc[3], A1, B1);
+            A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
+        }
+        mma_blk(acc[0], A0, B0);
+        if (use01) mma_blk(acc[1], A0, B1);
+        mma_blk(acc[2], A1, B0);
+        if (hasb1) mma_blk(acc[3], A1, B1);
+    } else {
+        mma_blk(acc[0], A0, B0);
+        if (use01) mma_blk(acc[1], A0, B1);
+    }
+    PROF_END(c, 6);
     float accl[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) accl[d] = 0.f;
     float accsf = 0.f, accsn = 0.f;
-    // groups (a-pair, b-pair) are dealt to the waves in a fixed "snake" order over the cost-sorted list (cost =
-    // NB - a0 steps): static => the summation order, hence the result, is reproducible bit for bit, and the
-    // waves finish together; consecutive groups share the a-pair, so the A blocks hit L1/L2
-    int gidx = 0;
-    for (int a0 = 0; a0 < NB; a0 += 2) {
-        const int a1 = a0 + 1;
-        const bool hasa1 = a1 < NB;
-        const int bmax = hasa1 ? a1 : a0;
-        for (int b0 = 0; b0 <= bmax; b0 += 2, ++gidx) {
-            const int rnd = gidx / NW, pos = gidx % NW;
-            if (((rnd & 1) ? (NW - 1 - pos) : pos) != c.w) continue;
-            PROF_BEGIN();
-            const int b1 = b0 + 1;
-            const bool hasb1 = b1 <= bmax;
-            TRACE(c, 70, a0);
-            const bool use01 = hasb1 && b1 <= a0;      // (a0, b1) is a lower block (false on the diagonal group)
-            f32x16 acc[4];
+    contract<D, KN>(c, acc[0], a0, b0, (a0 == b0) ? 1.f : 2.f, accl, accsf, accsn);
+    if (use01) contract<D, KN>(c, acc[1], a0, b1, (a0 == b1) ? 1.f : 2.f, accl, accsf, accsn);
+    if (hasa1) {
+        contract<D, KN>(c, acc[2], a1, b0, (a1 == b0) ? 1.f : 2.f, accl, accsf, accsn);
+        if (hasb1) contract<D, KN>(c, acc[3], a1, b1, (a1 == b1) ? 1.f : 2.f, accl, accsf, accsn);
+    }
+    const int base = c.gp0 + g * ((D + 2) * 256);          // bytes: [D + 2][64 lanes] floats per group
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[n] = zero16();
-            // M_cc,x lives at block cc*NB + x (cc >= x).  First step cc = a0: only row a0 exists (M_a0,a1 = 0)
-            f32x16 A0 = ldg(c.ws, a0 * NB + a0, lane);
-            f32x16 B0 = ldg(c.ws, a0 * NB + b0, lane);
-            f32x16 B1 = ldg(c.ws, use01 ? a0 * NB + b1 : c.zb, lane);
-            f32x16 A1 = A0;
-            if (a0 + 1 < NB) {
-                f32x16 nA0 = ldg(c.ws, a1 * NB + a0, lane);
-                f32x16 nA1 = ldg(c.ws, a1 * NB + a1, lane);
-                f32x16 nB0 = ldg(c.ws, a1 * NB + b0, lane);
-                f32x16 nB1 = ldg(c.ws, hasb1 ? a1 * NB + b1 : c.zb, lane);
-                mma_blk(acc[0], A0, B0);
-                if (use01) mma_blk(acc[1], A0, B1);
-                A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
-                for (int cc = a1; cc + 1 < NB; ++cc) {          // last step peeled, as in pt_group_kloop
-                    const int cn = cc + 1;
-                    nA0 = ldg(c.ws, cn * NB + a0, lane);
-                    nA1 = ldg(c.ws, cn * NB + a1, lane);
-                    nB0 = ldg(c.ws, cn * NB + b0, lane);
-                    nB1 = ldg(c.ws, hasb1 ? cn * NB + b1 : c.zb, lane);
-                    mma_blk(acc[0], A0, B0);
-                    if (use01) mma_blk(acc[1], A0, B1);
-                    mma_blk(acc[2], A1, B0);
-                    if (hasb1) mma_blk(acc[3], A1, B1);
-                    A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
-                }
-                mma_blk(acc[0], A0, B0);
-                if (use01) mma_blk(acc[1], A0, B1);
-                mma_blk(acc[2], A1, B0);
-                if (hasb1) mma_blk(acc[3], A1, B1);
-            } else {
-                mma_blk(acc[0], A0, B0);
-                if (use01) mma_blk(acc[1], A0, B1);
-            }
-            PROF_END(c, 6);
-            contract<D, KN>(c, acc[0], a0, b0, (a0 == b0) ? 1.f : 2.f, accl, accsf, accsn);
-            if (use01) contract<D, KN>(c, acc[1], a0, b1, (a0 == b1) ? 1.f : 2.f, accl, accsf, accsn);
-            if (hasa1) {
-                contract<D, KN>(c, acc[2], a1, b0, (a1 == b0) ? 1.f : 2.f, accl, accsf, accsn);
-                if (hasb1) contract<D, KN>(c, acc[3], a1, b1, (a1 == b1) ? 1.f : 2.f, accl, accsf, accsn);
-            }
-            PROF_END(c, 7);
-            TRACE(c, 71, a0);
+    for (int d = 0; d < D; ++d) st_part(c.ws, base + d * 256, lane, accl[d]);
+    st_part(c.ws, base + D * 256, lane, accsf);
+    st_part(c.ws, base + (D + 1) * 256, lane, accsn);
+    PROF_END(c, 7);
+    TRACE(c, 71, a0);
+}
+
+template <int D, int KN>
+__device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
+    Shared* sh = shared_state();
+    const int NB = c.NB, lane = c.lane;
+    const int NBp = (NB + 1) >> 1;
+    const int ngroups = NBp * (NBp + 1) / 2;
+    {
+        int ia = 0;
+        for (;;) {
+            const int g = wave_pull(&sh->gradnext, lane);           // zeroed by finish_nll
+            if (g >= ngroups) break;
+            while ((ia + 1) * (ia + 2) / 2 <= g) ++ia;
+            grad_group<D, KN>(c, g, ia, g - ia * (ia + 1) / 2);
         }
     }
-    // wave reduction (doubles), then across waves through LDS
+    // the partial sums of all groups are in memory: every wave's stores have completed before the barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        PROF_BEGIN();
+        __syncthreads();
+        PROF_END(c, 8);
+    }
+    // fixed-order sum: wave w adds the groups w, w + NW, ... per lane (fp64), then across lanes, then across waves
     double v[D + 2];
 #pragma unroll
-    for (int d = 0; d < D; ++d) v[d] = (double)accl[d];
-    v[D] = (double)accsf;
-    v[D + 1] = (double)accsn;
+    for (int i = 0; i < D + 2; ++i) v[i] = 0.0;
+    for (int g = c.w; g < ngroups; g += NW) {
+        const int base = c.gp0 + g * ((D + 2) * 256);
+        float f[D + 2];
+#pragma unroll
+        for (int i = 0; i < D + 2; ++i) f[i] = ld_part(c.ws, base + i * 256, lane);
+#pragma unroll
+        for (int i = 0; i < D + 2; ++i) v[i] += (double)f[i];
+    }
 #pragma unroll
     for (int i = 0; i < D + 2; ++i) {
 #pragma unroll
@@ -1113,11 +1159,7 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
 #pragma unroll
         for (int i = 0; i < D + 2; ++i) sh->red[c.w][i] = v[i];
     }
-    {
-        PROF_BEGIN();
-        __syncthreads();
-        PROF_END(c, 8);
-    }
+    __syncthreads();
     if (c.tid == 0) {
         for (int i = 0; i < D + 2; ++i) {
             double s = 0.0;
@@ -1144,6 +1186,7 @@ __device__ __forceinline__ void finish_nll(Ctx<D, KN>& c) {
         double s = 0.0;
         for (int ww = 0; ww < NW; ++ww) s += sh->red[ww][7];
         sh->nll = 0.5 * s + sh->logdet + 0.5 * (double)c.N * 1.8378770664093453;   // log(2 pi)
+        sh->gradnext = 0;                  // group queue of the gradient phase
     }
     __syncthreads();
 }
@@ -1372,6 +1415,7 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
         c.dT0 = NB * NB;
         c.vs0 = c.dT0 + NB;
         c.cv0 = c.vs0 + NW * 2 * NB;
+        c.gp0 = c.vs0 * (BLK * 4);
         if (c.N == 0) {
             if (c.tid == 0) {
                 A.status[t] = 4; A.n_eval[t] = 0; A.nll[t] = 0.0;
