@@ -61,7 +61,7 @@ struct gpsat_handle {
     double last_kernel_ms = 0.0, last_total_ms = 0.0;
     bool force_unsliced = false;       // retry of a batch whose time-sliced queue ended with unfinished tiles
     // device buffers (grown lazily, owned by the handle)
-    DevBuf meta_i64, meta_f64, meta_misc, out_f64, out_i32, bulk_in, bulk_out, ws, prof, ring, state;
+    DevBuf meta_i64, meta_f64, meta_misc, out_f64, out_i32, bulk_in, bulk_out, ws, prof, ring, state, coop;
     DevBuf sel_pts, sel_refs, sel_cnt, sel_idx, sel_box;
     unsigned long long prof_host[64 + 8 * 1024 + 2048] = {0};     // counters + event trace + per-workgroup start / end (diagnostic build)
 };
@@ -127,7 +127,7 @@ int gpsat_destroy(gpsat_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->meta_i64.release(); h->meta_f64.release(); h->meta_misc.release(); h->out_f64.release();
-    h->out_i32.release(); h->bulk_in.release(); h->bulk_out.release(); h->ws.release(); h->prof.release(); h->ring.release(); h->state.release();
+    h->out_i32.release(); h->bulk_in.release(); h->bulk_out.release(); h->ws.release(); h->prof.release(); h->ring.release(); h->state.release(); h->coop.release();
     h->sel_pts.release(); h->sel_refs.release(); h->sel_cnt.release(); h->sel_idx.release(); h->sel_box.release();
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -222,6 +222,25 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
                             : (w8 ? gpsat::shared_bytes_w8(D, NBmax) : gpsat::shared_bytes(D, NBmax));
     if (smem > 160 * 1024) return fail(GPSAT_EINVAL, "tile too large for LDS");
     if (w8 || (f64 && !d4)) grid = std::min(grid, h->num_cu);
+    // cooperative tiles (fp32 kernels): a workgroup without a tile helps a running one (gpsat_coop.h).  With fewer tiles than
+    // resident workgroups the launch is widened by the helpers the large tiles can use.
+    bool coop = !f64;
+    int coop_min_nb = 12;
+    int coop_force = 0;
+    if (const char* e = std::getenv("GPSAT_DEBUG_COOP")) {           // developer: 0 = off, 2 = cooperative code path always
+        coop = coop && std::atoi(e) != 0;
+        coop_force = std::atoi(e) == 2;
+    }
+    if (const char* e = std::getenv("GPSAT_DEBUG_COOP_MIN_NB")) coop_min_nb = std::max(2, std::atoi(e));
+    if (coop) {
+        const int cap = (w8 ? 1 : h->wg_per_cu) * h->num_cu;
+        long long want = grid;
+        for (int t = 0; t < T && want < cap; ++t) {
+            const int nb = (int)((b->obs_off[t + 1] - b->obs_off[t] + bs - 1) / bs);
+            if (nb >= coop_min_nb) want += std::min(7, std::max(1, nb / 12));
+        }
+        if (T < cap) grid = (int)std::min<long long>(cap, want);
+    }
     if (const char* e = std::getenv("GPSAT_DEBUG_GRID")) grid = std::max(1, std::min(grid, std::atoi(e)));   // developer: fewer resident workgroups
     if ((rc = h->ws.reserve((size_t)grid * wsf * esz))) return rc;
 
@@ -304,6 +323,16 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     }
 
     gpsat::KernelArgs a;
+    a.coop = nullptr; a.coop_live = nullptr; a.coop_min_nb = coop_min_nb; a.coop_force = coop_force;
+    if (coop) {
+        // [grid] control blocks of 1 KiB, zeroed every launch, then the count of unfinished tiles
+        const size_t cb = (size_t)grid * 1024;
+        if ((rc = h->coop.reserve(cb + 64))) return rc;
+        HIP_TRY(hipMemsetAsync(h->coop.p, 0, cb + 64, h->stream));
+        HIP_TRY(hipMemcpyAsync(static_cast<char*>(h->coop.p) + cb, &b->T, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        a.coop = h->coop.p;
+        a.coop_live = reinterpret_cast<int*>(static_cast<char*>(h->coop.p) + cb);
+    }
     a.ring = d_ring; a.ring_ctl = d_ring_ctl; a.state = d_state; a.ring_mask = ring_mask; a.state_words = state_words; a.seg_cost = seg_cost;
     a.T = T; a.kernel = b->kernel; a.optimiser = b->optimiser; a.max_iter = b->max_iter;
     a.max_ls = b->max_ls > 0 ? b->max_ls : 20;                                 // SciPy L-BFGS-B maxls

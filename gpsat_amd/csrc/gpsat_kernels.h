@@ -44,6 +44,12 @@ struct KernelArgs {
     int* ring_ctl;                // [0] pop counter, [16] push counter (preset T), [32] unfinished tiles (preset T)
     unsigned* state;              // [T][state_words] saved optimiser state (the kernel's Shared struct)
     int ring_mask, state_words, seg_cost;
+    // cooperative tiles (nullptr: off): one CoopCtl per workgroup (gpsat_coop.h), zeroed before the launch; workgroups that
+    // find no tile left attach themselves to a running tile and pull groups of its sweep / gradient queues
+    void* coop;                   // [grid] CoopCtl
+    int* coop_live;               // tiles not finished yet (preset T): the helpers' exit condition
+    int coop_min_nb;              // smallest tile (block columns) worth helping
+    int coop_force;               // developer / tests: every evaluation of a helpable tile runs the cooperative code path, helped or not
 };
 
 size_t shared_bytes(int D, int NBmax);

@@ -213,6 +213,7 @@ __device__ __forceinline__ void kfun(float r2, float& kf, float& gg) {
 
 #define GPSAT_PT_MAXNB 100      // block columns of the largest tile (gpsat_max_tile_obs: 3168 = 99 * 32)
 #include "gpsat_opt.h"
+#include "gpsat_coop.h"
 
 constexpr int SHARED_FLOATS = (int)((sizeof(Shared) + 15) / 16) * 4;
 
@@ -227,6 +228,12 @@ struct Ctx {
     float* ws;                   // this workgroup's global workspace
     int zb, dT0, vs0, cv0;       // block indices: zero block, DinvT[0], V scratch, V of all chunks (full covariance)
     int gp0;                     // byte offset of the gradient phase's per-group partial sums (aliases the V scratch)
+    // cooperative tiles (gpsat_coop.h): the control block of the tile's OWNER, z and alpha of the open evaluation in the
+    // owner's workspace, and whether this workgroup is a helper of that owner
+    gCoopCtl* ctl;
+    gfloat* zg;
+    gfloat* ag;
+    bool helper;
     int N, NB, Npad, P;
     int tid, lane, w, h, g;
     float sf2, sn2;
@@ -615,15 +622,17 @@ __device__ __forceinline__ void pt_group_kloop(const Ctx<D, KN>& c, const Panel<
 // `par` selects the LDS copy of the panel's factors (double-buffered across panels, see phase_pt).
 // apsum[n]: item n's contribution to alpha (M-type items), summed over the panel's rows and added to alpha ONCE after the
 // last row -- one read-modify-write per group and column, whoever runs the group.
-template <int D, int KN>
+// COOP: the panel's factors come from the workspace (where the chain stores the same values it keeps in LDS for its own
+// workgroup), alpha lives in the owner's workspace.
+template <int D, int KN, bool COOP>
 __device__ __forceinline__ void pt_group_row(const Ctx<D, KN>& c, const Panel<D>& p, int g, int r, int par, f32x16 (&W)[4],
                                              float (&apsum)[2]) {
     const int NB = c.NB, lane = c.lane;
     const int jr = p.j0 + r;
-    const f32x16 Lop = ldl(c.L.LT + (2 * par + r) * BLK, lane);
+    const f32x16 Lop = COOP ? ldg(c.ws, c.dT0 + jr, lane) : ldl(c.L.LT + (2 * par + r) * BLK, lane);
     f32x16 U01 = Lop;
     const bool fold = (r == 0) && p.has1;
-    if (fold) U01 = ldl(c.L.U01 + par * BLK, lane);
+    if (fold) U01 = COOP ? ldg(c.ws, p.j0 * NB + p.j1, lane) : ldl(c.L.U01 + par * BLK, lane);
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int e = 2 * g + n;
@@ -641,7 +650,16 @@ __device__ __forceinline__ void pt_group_row(const Ctx<D, KN>& c, const Panel<D>
                 for (int q = 0; q < 16; ++q) ap = fmaf(X[q], lds_f[c.L.z + 32 * jr + rho(q, c.h)], ap);
                 ap = xhalf_sum(ap);
                 apsum[n] = (r == 0) ? ap : apsum[n] + ap;
-                if (r == p.has1 && c.h == 0) lds_f[c.L.alpha + 32 * col + c.g] += apsum[n];
+                if (r == p.has1 && c.h == 0) {
+                    if (COOP) {
+                        // ordered against the other updates of this column by colrow (release after the drain below,
+                        // acquire = the sc1 poll of the next group that owns the column)
+                        gfloat* a = c.ag + 32 * col + c.g;
+                        gst_f(a, gld_f(a) + apsum[n]);
+                    } else {
+                        lds_f[c.L.alpha + 32 * col + c.g] += apsum[n];
+                    }
+                }
             }
             if (fold) {
                 f32x16 T = zero16();
@@ -650,6 +668,21 @@ __device__ __forceinline__ void pt_group_row(const Ctx<D, KN>& c, const Panel<D>
             }
         }
     }
+}
+
+// spin on a flag of the sweep in the owner's control block (cooperative evaluation); false = failed, unwind
+__device__ __forceinline__ bool pt_wait_g(gCoopCtl* ctl, const gint* flag, int v) {
+    int spins = 0;
+    while (__hip_atomic_load(flag, RLX_AGENT) < v) {
+        __builtin_amdgcn_s_sleep(8);
+        if ((++spins & 7) == 0 && __hip_atomic_load(&ctl->fail, RLX_AGENT)) return false;
+        if (spins > (1 << 21)) {             // never reached by design (seconds); a lost flag must not hang the GPU
+            __hip_atomic_store(&ctl->fail, 2, RLX_AGENT);
+            return false;
+        }
+    }
+    asm volatile("" ::: "memory");           // the data behind the flag is read with sc1 loads only: no invalidate needed
+    return true;
 }
 
 // spin on a flag of the sweep (see phase_pt); false = the evaluation has failed, unwind
@@ -666,6 +699,37 @@ __device__ __forceinline__ bool pt_wait(Shared* sh, const int* flag, int v) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     return true;
 }
+
+// owner-local flag (LDS) of a cooperative evaluation: also gives up when a helper has failed the evaluation
+__device__ __forceinline__ bool pt_wait_lc(Shared* sh, gCoopCtl* ctl, const int* flag, int v) {
+    int spins = 0;
+    while (__hip_atomic_load(flag, RLX_WG) < v) {
+        if (__hip_atomic_load(&sh->fail, RLX_WG)) return false;
+        __builtin_amdgcn_s_sleep(2);
+        ++spins;
+        if (((spins & 63) == 0 && __hip_atomic_load(&ctl->fail, RLX_AGENT)) || spins > (1 << 22)) {
+            __hip_atomic_store(&sh->fail, 2, RLX_WG);
+            return false;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return true;
+}
+
+// sweep flags that helpers see live in the owner's control block during a cooperative evaluation, in LDS otherwise
+#define PTW(field, v) (COOP ? pt_wait_g(c.ctl, &c.ctl->field, (v)) : pt_wait(sh, &sh->field, (v)))
+#define PTW_LOCAL(field, v) (COOP ? pt_wait_lc(sh, c.ctl, &sh->field, (v)) : pt_wait(sh, &sh->field, (v)))
+#define PTS(field, v)                                                                     \
+    do {                                                                                  \
+        if (COOP) __hip_atomic_store(&c.ctl->field, (v), RLX_AGENT);                      \
+        else __hip_atomic_store(&sh->field, (v), RLX_WG);                                 \
+    } while (0)
+// before a flag that announces this wave's stores
+#define PT_RELEASE()                                                                      \
+    do {                                                                                  \
+        if (COOP) coop_drain();                                                           \
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                       \
+    } while (0)
 
 // D00 += U_k,j0^T U_k,j0, D01 += U_k,j0^T U_k,j1, D11 += U_k,j1^T U_k,j1 and the forward-solve partials for k in [kb, ke)
 template <int D, int KN>
@@ -699,7 +763,7 @@ __device__ __forceinline__ void chain_kloop(const Ctx<D, KN>& c, const Panel<D>&
 // `slot` is the panel's index.  kwait: rows >= kwait of the panel columns (= the rows of the previous panel) arrive
 // last: parked as a finished k-loop by the column wave (`held`: the chain completes them itself) or, in the tail, written
 // by it (the chain then waits for sh->g0done >= slot).  Returns false when the evaluation has failed (waits unwound).
-template <int D, int KN>
+template <int D, int KN, bool COOP>
 __device__ __forceinline__ bool pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const Panel<D>& q, const bool want_m, int par,
                                          int kwait, int slot, bool held, int lt_users) {
     Shared* sh = shared_state();
@@ -712,8 +776,8 @@ __device__ __forceinline__ bool pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const
     TRACE(c, 1, slot);
     // rows of the panels <= slot-2 of this panel's two columns (the column wave's group 1 of panel slot-2 was the last)
     if (slot >= 2) {
-        if (!pt_wait(sh, &sh->colrow[j0], slot - 1)) return false;
-        if (has1 && !pt_wait(sh, &sh->colrow[j1], slot - 1)) return false;
+        if (!PTW(colrow[j0], slot - 1)) return false;
+        if (has1 && !PTW(colrow[j1], slot - 1)) return false;
     }
     PROF_END(c, 10);
     // the chain is the critical path of the sweep: let it win VALU / LDS issue arbitration against the
@@ -725,13 +789,13 @@ __device__ __forceinline__ bool pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const
     if (kwait < j0 && !held) {
         // group 0 of the previous panel is finished by the column wave: wait for its rows
         PROF_END(c, 0);
-        if (!pt_wait(sh, &sh->g0done, slot)) { __builtin_amdgcn_s_setprio(0); return false; }
+        if (!PTW(g0done, slot)) { __builtin_amdgcn_s_setprio(0); return false; }
         PROF_END(c, 10);
         chain_kloop<D, KN>(c, p, kwait, j0, D00, D01, D11, tp0, tp1);
     }
     if (kwait < j0 && held) {
         PROF_END(c, 0);
-        if (!pt_wait(sh, &sh->parked, slot)) { __builtin_amdgcn_s_setprio(0); return false; }
+        if (!PTW_LOCAL(parked, slot)) { __builtin_amdgcn_s_setprio(0); return false; }
         PROF_END(c, 10);
         TRACE(c, 4, slot);
         // Rows j0-2, j0-1 of this panel's two columns = group 0 of the previous panel q (both items U-type), whose k-loop the column
@@ -773,13 +837,14 @@ __device__ __forceinline__ bool pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const
             tp1 = fmaf(X0[1][qq], z0, fmaf(X1[1][qq], z1, tp1));
         }
         // the column wave needs these rows for the k-loop it runs ahead at the end of this slot
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(&sh->g0done, slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        PT_RELEASE();
+        if (lane == 0) PTS(g0done, slot);
     }
     PROF_END(c, 0);
     TRACE(c, 5, slot);
-    // the factor copies of this parity still serve the groups of panel slot-2
-    if (slot >= 2) {
+    // the factor copies of this parity still serve the groups of panel slot-2 (cooperative evaluation: every group reads
+    // the factors from the workspace, the LDS copies serve this chain alone)
+    if (slot >= 2 && !COOP) {
         if (!pt_wait(sh, &sh->gdone[par], lt_users)) { __builtin_amdgcn_s_setprio(0); return false; }
         if (lane == 0) __hip_atomic_store(&sh->gdone[par], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         PROF_END(c, 10);
@@ -821,8 +886,14 @@ __device__ __forceinline__ bool pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const
 #pragma unroll
         for (int q = 0; q < 16; ++q) zz = fmaf(S2[q], lds_f[c.L.tmp + rho(q, c.h)], zz);
         zz = xhalf_sum(zz);
-        if (c.h == 0) lds_f[c.L.z + 32 * jr + c.g] = zz;
-        if (lane == 0) { sh->logdet += ls; if (bad) sh->fail = 1; }
+        if (c.h == 0) {
+            lds_f[c.L.z + 32 * jr + c.g] = zz;
+            if (COOP) gst_f(c.zg + 32 * jr + c.g, zz);
+        }
+        if (lane == 0) {
+            sh->logdet += ls;
+            if (bad) { sh->fail = 1; if (COOP) __hip_atomic_store(&c.ctl->fail, 1, RLX_AGENT); }
+        }
         wave_lds_sync();
         if (want_m) {
             // alpha_jr += M_jrjr^T z_jr
@@ -830,7 +901,10 @@ __device__ __forceinline__ bool pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const
 #pragma unroll
             for (int q = 0; q < 16; ++q) ap = fmaf(S1[q], lds_f[c.L.z + 32 * jr + rho(q, c.h)], ap);
             ap = xhalf_sum(ap);
-            if (c.h == 0) lds_f[c.L.alpha + 32 * jr + c.g] += ap;
+            if (c.h == 0) {
+                if (COOP) { gfloat* a = c.ag + 32 * jr + c.g; gst_f(a, gld_f(a) + ap); }
+                else lds_f[c.L.alpha + 32 * jr + c.g] += ap;
+            }
         }
         if (r == 0) {
             S1keep = S1;
@@ -855,16 +929,19 @@ __device__ __forceinline__ bool pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const
 #pragma unroll
             for (int q = 0; q < 16; ++q) ap = fmaf(Mx[q], lds_f[c.L.z + 32 * j1 + rho(q, c.h)], ap);
             ap = xhalf_sum(ap);
-            if (c.h == 0) lds_f[c.L.alpha + 32 * j0 + c.g] += ap;
+            if (c.h == 0) {
+                if (COOP) { gfloat* a = c.ag + 32 * j0 + c.g; gst_f(a, gld_f(a) + ap); }
+                else lds_f[c.L.alpha + 32 * j0 + c.g] += ap;
+            }
         }
     }
     __builtin_amdgcn_s_setprio(0);
-    // publish: factors (LDS), diagonal blocks, U_j0j1, M_j1j0, z are in place; the panel's columns are complete
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // publish: factors (LDS + workspace), diagonal blocks, U_j0j1, M_j1j0, z are in place; the panel's columns are complete
+    PT_RELEASE();
     if (lane == 0) {
-        __hip_atomic_store(&sh->colrow[j0], slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (has1) __hip_atomic_store(&sh->colrow[j1], slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_store(&sh->ready, slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        PTS(colrow[j0], slot + 1);
+        if (has1) PTS(colrow[j1], slot + 1);
+        PTS(ready, slot + 1);
     }
     PROF_END(c, 2);
     TRACE(c, 9, slot);
@@ -900,19 +977,20 @@ __device__ __forceinline__ Panel<D> make_panel(int NB, int pi, bool want_m) {
 template <int D>
 __device__ __forceinline__ int pt_lt_users(const Panel<D>& q) { return ((q.nItems + 1) >> 1) - (q.nU >= 2 ? 1 : 0); }
 
-// one group of panel q (index sq): wait for its columns, k-loop, wait for the panel's factors, row solves, publish
-template <int D, int KN>
-__device__ __forceinline__ bool pt_run_group(const Ctx<D, KN>& c, const Panel<D>& q, int sq, int g) {
+// one group of panel q (index sq): wait for its columns, k-loop, wait for the panel's factors, row solves, publish.
+// `queued`: the group came from the bulk queue (cooperative evaluation: counted in ctl->done).
+template <int D, int KN, bool COOP>
+__device__ __forceinline__ bool pt_run_group(const Ctx<D, KN>& c, const Panel<D>& q, int sq, int g, bool queued) {
     Shared* sh = shared_state();
     PROF_BEGIN();
     TRACE(c, 20, sq * 16 + g);
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int e = 2 * g + n;
-        if (e < q.nItems && !pt_wait(sh, &sh->colrow[pt_item_col(q, e)], sq)) return false;
+        if (e < q.nItems && !PTW(colrow[pt_item_col(q, e)], sq)) return false;
     }
     // ... and of the panel's own two columns (their rows of panel sq-1 come last: group 0 of that panel)
-    if (sq >= 1 && !pt_wait(sh, &sh->g0done, sq)) return false;
+    if (sq >= 1 && !PTW(g0done, sq)) return false;
     PROF_END(c, 3);
     TRACE(c, 21, sq * 16 + g);
     f32x16 W[4];
@@ -920,27 +998,107 @@ __device__ __forceinline__ bool pt_run_group(const Ctx<D, KN>& c, const Panel<D>
     PROF_END(c, 4);
     TRACE(c, 22, sq * 16 + g);
     // only the row solves need the panel's own factors: the k-loop above ran while its chain may still be at work
-    if (!pt_wait(sh, &sh->ready, sq + 1)) return false;
+    if (!PTW(ready, sq + 1)) return false;
+    if (COOP && c.helper && 2 * g + 1 >= q.nU) {
+        // a helper has no z of its own: the panel's two rows of z (written by the owner's chain before `ready`) come from the
+        // owner's workspace into this workgroup's LDS (several waves may copy the same values at once)
+        const int i = 32 * q.j0 + c.lane;
+        if (i < c.Npad) lds_f[c.L.z + i] = gld_f(c.zg + i);
+        wave_lds_sync();
+    }
     PROF_END(c, 3);
     TRACE(c, 24, sq * 16 + g);
     float apsum[2] = {0.f, 0.f};
-    pt_group_row<D, KN>(c, q, g, 0, sq & 1, W, apsum);
-    if (q.has1) pt_group_row<D, KN>(c, q, g, 1, sq & 1, W, apsum);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    pt_group_row<D, KN, COOP>(c, q, g, 0, sq & 1, W, apsum);
+    if (q.has1) pt_group_row<D, KN, COOP>(c, q, g, 1, sq & 1, W, apsum);
+    PT_RELEASE();
     if (c.lane == 0) {
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int e = 2 * g + n;
-            if (e < q.nItems) __hip_atomic_store(&sh->colrow[pt_item_col(q, e)], sq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (e < q.nItems) PTS(colrow[pt_item_col(q, e)], sq + 1);
         }
-        __hip_atomic_fetch_add(&sh->gdone[sq & 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (COOP) { if (queued) __hip_atomic_fetch_add(&c.ctl->done, 1, RLX_AGENT); }
+        else __hip_atomic_fetch_add(&sh->gdone[sq & 1], 1, RLX_WG);
     }
     PROF_END(c, 5);
     TRACE(c, 23, sq * 16 + g);
     return true;
 }
 
-template <int D, int KN>
+// groups of the bulk queue: groups >= 2 of every panel, panel-major; nobody waits for the last panel's groups 0 and 1, so
+// they are queued as well
+template <int D>
+__device__ __forceinline__ int pt_queue_len(int NB, bool want_m) {
+    const int NP = (NB + 1) >> 1;
+    int tot = 0;
+    for (int s = 0; s < NP; ++s) {
+        const Panel<D> q = make_panel<D>(NB, s, want_m);
+        tot += max(0, ((q.nItems + 1) >> 1) - ((s == NP - 1) ? 0 : 2));
+    }
+    return tot;
+}
+
+// the bulk loop of one wave: pull group indices until the queue is exhausted (owner and helpers alike)
+template <int D, int KN, bool COOP>
+__device__ __forceinline__ bool pt_bulk_loop(const Ctx<D, KN>& c, const bool want_m, bool ok) {
+    Shared* sh = shared_state();
+    const int NB = c.NB;
+    const int NP = (NB + 1) >> 1;
+    int sq = 0, base = 0;
+    Panel<D> q = make_panel<D>(NB, 0, want_m);
+    int g0 = (NP == 1) ? 0 : 2;
+    int nq = max(0, ((q.nItems + 1) >> 1) - g0);
+    while (ok) {
+        int idx;
+        if (COOP) {
+            int v = 0;
+            if (c.lane == 0) v = __hip_atomic_fetch_add(&c.ctl->qhead, 1, RLX_AGENT);
+            idx = __builtin_amdgcn_readfirstlane(v);
+        } else {
+            idx = wave_pull(&sh->qhead, c.lane);
+        }
+        while (sq < NP && idx >= base + nq) {
+            base += nq;
+            ++sq;
+            if (sq < NP) {
+                q = make_panel<D>(NB, sq, want_m);
+                g0 = (sq == NP - 1) ? 0 : 2;
+                nq = max(0, ((q.nItems + 1) >> 1) - g0);
+            }
+        }
+        if (sq >= NP) break;
+        TRACE(c, 50, sq);
+        ok = pt_run_group<D, KN, COOP>(c, q, sq, g0 + idx - base, true);
+    }
+    return ok;
+}
+
+// bounded wait of the owner's thread 0 for a counter of its control block
+__device__ __forceinline__ bool coop_wait_eq(gCoopCtl* ctl, const gint* word, int v) {
+    for (int spins = 0; __hip_atomic_load(word, RLX_AGENT) != v; ++spins) {
+        __builtin_amdgcn_s_sleep(8);
+        if (spins > (1 << 21) || ((spins & 15) == 15 && word != &ctl->active && __hip_atomic_load(&ctl->fail, RLX_AGENT))) return false;
+    }
+    return true;
+}
+
+// owner, thread 0: open a phase of the cooperative evaluation (everything the helpers read has been stored and drained)
+__device__ __forceinline__ void coop_open(Shared* sh, gCoopCtl* ctl, int kind) {
+    sh->coop_seq += 1;
+    __hip_atomic_store(&ctl->phase, ((unsigned)sh->coop_seq << 2) | (unsigned)kind, RLX_AGENT);
+}
+
+// owner, thread 0: all `total` queue groups done (or the evaluation failed), then close the phase and wait until the helpers
+// that checked in have checked out.  Returns false when a wait gave up.
+__device__ __forceinline__ bool coop_close(Shared* sh, gCoopCtl* ctl, int total) {
+    bool ok = coop_wait_eq(ctl, &ctl->done, total);
+    __hip_atomic_store(&ctl->phase, ((unsigned)sh->coop_seq << 2) | (unsigned)COOP_CLOSED, RLX_AGENT);
+    if (!coop_wait_eq(ctl, &ctl->active, 0)) ok = false;
+    return ok;
+}
+
+template <int D, int KN, bool COOP>
 __device__ __forceinline__ void phase_pt(Ctx<D, KN>& c, const bool want_m) {
     Shared* sh = shared_state();
     const int NB = c.NB, w = c.w;
@@ -951,6 +1109,23 @@ __device__ __forceinline__ void phase_pt(Ctx<D, KN>& c, const bool want_m) {
     }
     for (int idx = c.tid; idx < NB; idx += NT) sh->colrow[idx] = 0;
     for (int idx = c.tid; idx < c.Npad; idx += NT) lds_f[c.L.alpha + idx] = 0.f;
+    if (COOP) {
+        // the flags, counters and alpha of this evaluation in the control block / workspace, then the phase word: helpers
+        // touch none of them before they have seen the new phase, and no helper of an earlier phase is left (coop_close)
+        if (c.tid == 0) {
+            __hip_atomic_store(&c.ctl->ready, 0, RLX_AGENT);
+            __hip_atomic_store(&c.ctl->g0done, 0, RLX_AGENT);
+            __hip_atomic_exchange(&c.ctl->qhead, 0, RLX_AGENT);
+            __hip_atomic_exchange(&c.ctl->done, 0, RLX_AGENT);
+            __hip_atomic_exchange(&c.ctl->fail, 0, RLX_AGENT);
+            __hip_atomic_store(&c.ctl->want_m, want_m ? 1 : 0, RLX_AGENT);
+        }
+        for (int idx = c.tid; idx < NB; idx += NT) __hip_atomic_store(&c.ctl->colrow[idx], 0, RLX_AGENT);
+        for (int idx = c.tid; idx < c.Npad; idx += NT) gst_f(c.ag + idx, 0.f);
+        coop_drain();
+        __syncthreads();
+        if (c.tid == 0) coop_open(sh, c.ctl, COOP_SWEEP);
+    }
     __syncthreads();
     bool ok = true;
     if (w == 0) {
@@ -960,8 +1135,8 @@ __device__ __forceinline__ void phase_pt(Ctx<D, KN>& c, const bool want_m) {
             const int kwait = (s > 0) ? (p.j0 - 2) : p.j0;
             const bool held = (s > 0) && (q.nU >= 2);
             const int users = (s >= 2) ? pt_lt_users<D>(make_panel<D>(NB, s - 2, want_m)) : 0;
-            ok = pt_chain<D, KN>(c, p, q, want_m, s & 1, kwait, s, held, users);
-            if (ok && __hip_atomic_load(&sh->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) ok = false;
+            ok = pt_chain<D, KN, COOP>(c, p, q, want_m, s & 1, kwait, s, held, users);
+            if (ok && __hip_atomic_load(&sh->fail, RLX_WG)) ok = false;
         }
     } else if (w == 1) {
         for (int s = 0; s < NP && ok; ++s) {
@@ -970,20 +1145,20 @@ __device__ __forceinline__ void phase_pt(Ctx<D, KN>& c, const bool want_m) {
                 const int nGroups = (q.nItems + 1) >> 1;
                 if (ok && nGroups > 0 && q.nU < 2) {
                     // tail: group 0 was not parked; the chain of panel s waits for these rows
-                    ok = pt_run_group<D, KN>(c, q, s - 1, 0);
-                    if (ok && c.lane == 0) __hip_atomic_store(&sh->g0done, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    ok = pt_run_group<D, KN, COOP>(c, q, s - 1, 0, false);
+                    if (ok && c.lane == 0) PTS(g0done, s);
                 }
-                if (ok && nGroups > 1) ok = pt_run_group<D, KN>(c, q, s - 1, 1);
+                if (ok && nGroups > 1) ok = pt_run_group<D, KN, COOP>(c, q, s - 1, 1, false);
             }
             if (ok && s < NP) {
                 // run ahead: k-loop of group 0 of panel s (the columns of the next chain), parked in LDS for that chain
                 const Panel<D> pn = make_panel<D>(NB, s, want_m);
                 if (pn.nU >= 2) {
                     PROF_BEGIN();
-                    ok = pt_wait(sh, &sh->colrow[pn.j1 + 1], s) && pt_wait(sh, &sh->colrow[pn.j1 + 2], s);
+                    ok = PTW(colrow[pn.j1 + 1], s) && PTW(colrow[pn.j1 + 2], s);
                     // rows of panel s-1 of the columns j0(s), j1(s): written by the chain of panel s (or above, in the tail)
-                    if (ok && s >= 1) ok = pt_wait(sh, &sh->g0done, s);
-                    if (ok) ok = pt_wait(sh, &sh->whfree, s);
+                    if (ok && s >= 1) ok = PTW(g0done, s);
+                    if (ok) ok = PTW_LOCAL(whfree, s);
                     PROF_END(c, 3);
                     TRACE(c, 30, s);
                     if (ok) {
@@ -992,7 +1167,7 @@ __device__ __forceinline__ void phase_pt(Ctx<D, KN>& c, const bool want_m) {
 #pragma unroll
                         for (int n = 0; n < 4; ++n) stl(c.L.Wh + n * BLK, c.lane, W[n]);
                         wave_lds_sync();
-                        if (c.lane == 0) __hip_atomic_store(&sh->parked, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (c.lane == 0) __hip_atomic_store(&sh->parked, s + 1, RLX_WG);
                         PROF_END(c, 4);
                         TRACE(c, 31, s);
                     }
@@ -1000,31 +1175,26 @@ __device__ __forceinline__ void phase_pt(Ctx<D, KN>& c, const bool want_m) {
             }
         }
     }
-    // the bulk queue: groups >= 2 of every panel, panel-major; nobody waits for the last panel's groups 0 and 1, so they
-    // are queued as well
-    {
-        int sq = 0, base = 0;
-        Panel<D> q = make_panel<D>(NB, 0, want_m);
-        int g0 = (NP == 1) ? 0 : 2;
-        int nq = max(0, ((q.nItems + 1) >> 1) - g0);
-        while (ok) {
-            const int idx = wave_pull(&sh->qhead, c.lane);
-            while (sq < NP && idx >= base + nq) {
-                base += nq;
-                ++sq;
-                if (sq < NP) {
-                    q = make_panel<D>(NB, sq, want_m);
-                    g0 = (sq == NP - 1) ? 0 : 2;
-                    nq = max(0, ((q.nItems + 1) >> 1) - g0);
-                }
-            }
-            if (sq >= NP) break;
-            TRACE(c, 50, sq);
-            ok = pt_run_group<D, KN>(c, q, sq, g0 + idx - base);
-        }
+    ok = pt_bulk_loop<D, KN, COOP>(c, want_m, ok);
+    if (COOP && !ok && c.lane == 0) {
+        // a wave of the owner unwinds: everybody else must, too
+        __hip_atomic_store(&sh->fail, 2, RLX_WG);
+        __hip_atomic_store(&c.ctl->fail, 2, RLX_AGENT);
     }
     TRACE(c, 60, 0);
     __syncthreads();
+    if (COOP) {
+        // the helpers' groups are part of this sweep: all queue groups done, phase closed, helpers out; then alpha (and a
+        // failure a helper met) come home
+        if (c.tid == 0) {
+            if (!coop_close(sh, c.ctl, pt_queue_len<D>(NB, want_m)) && !sh->fail) sh->fail = 2;
+            if (__hip_atomic_load(&c.ctl->fail, RLX_AGENT) && !sh->fail) sh->fail = 2;
+        }
+        __syncthreads();
+        if (want_m && !sh->fail)
+            for (int idx = c.tid; idx < c.Npad; idx += NT) lds_f[c.L.alpha + idx] = gld_f(c.ag + idx);
+        __syncthreads();
+    }
     TRACE(c, 61, 0);
 }
 
@@ -1116,27 +1286,58 @@ __device__ __forceinline__ void grad_group(const Ctx<D, KN>& c, int g, int ia, i
     TRACE(c, 71, a0);
 }
 
-template <int D, int KN>
+// the group loop of one wave (owner and helpers alike)
+template <int D, int KN, bool COOP>
+__device__ __forceinline__ void grad_loop(const Ctx<D, KN>& c) {
+    Shared* sh = shared_state();
+    const int NBp = (c.NB + 1) >> 1;
+    const int ngroups = NBp * (NBp + 1) / 2;
+    int ia = 0;
+    for (;;) {
+        int g;
+        if (COOP) {
+            int v = 0;
+            if (c.lane == 0) v = __hip_atomic_fetch_add(&c.ctl->qhead, 1, RLX_AGENT);
+            g = __builtin_amdgcn_readfirstlane(v);
+        } else {
+            g = wave_pull(&sh->gradnext, c.lane);                    // zeroed by finish_nll
+        }
+        if (g >= ngroups) break;
+        while ((ia + 1) * (ia + 2) / 2 <= g) ++ia;
+        grad_group<D, KN>(c, g, ia, g - ia * (ia + 1) / 2);
+        if (COOP) {
+            coop_drain();
+            if (c.lane == 0) __hip_atomic_fetch_add(&c.ctl->done, 1, RLX_AGENT);
+        }
+    }
+}
+
+template <int D, int KN, bool COOP>
 __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
     Shared* sh = shared_state();
     const int NB = c.NB, lane = c.lane;
     const int NBp = (NB + 1) >> 1;
     const int ngroups = NBp * (NBp + 1) / 2;
-    {
-        int ia = 0;
-        for (;;) {
-            const int g = wave_pull(&sh->gradnext, lane);           // zeroed by finish_nll
-            if (g >= ngroups) break;
-            while ((ia + 1) * (ia + 2) / 2 <= g) ++ia;
-            grad_group<D, KN>(c, g, ia, g - ia * (ia + 1) / 2);
+    if (COOP) {
+        if (c.tid == 0) {
+            __hip_atomic_exchange(&c.ctl->qhead, 0, RLX_AGENT);
+            __hip_atomic_exchange(&c.ctl->done, 0, RLX_AGENT);
+            coop_drain();
+            coop_open(sh, c.ctl, COOP_GRAD);
         }
+        __syncthreads();
     }
+    grad_loop<D, KN, COOP>(c);
     // the partial sums of all groups are in memory: every wave's stores have completed before the barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     {
         PROF_BEGIN();
         __syncthreads();
         PROF_END(c, 8);
+    }
+    if (COOP) {
+        if (c.tid == 0 && !coop_close(sh, c.ctl, ngroups)) sh->fail = 2;
+        __syncthreads();
     }
     // fixed-order sum: wave w adds the groups w, w + NW, ... per lane (fp64), then across lanes, then across waves
     double v[D + 2];
@@ -1192,7 +1393,7 @@ __device__ __forceinline__ void finish_nll(Ctx<D, KN>& c) {
 }
 
 // one objective (+ gradient) evaluation at sh->theta.  On return sh->nll, sh->gth, sh->fail are set.
-template <int D, int KN>
+template <int D, int KN, bool COOP>
 __device__ __forceinline__ void evaluate(Ctx<D, KN>& c, bool want_grad) {
     Shared* sh = shared_state();
     __syncthreads();
@@ -1210,14 +1411,23 @@ __device__ __forceinline__ void evaluate(Ctx<D, KN>& c, bool want_grad) {
     // (Experiment E17: not joining the sweep before the gradient phase -- K^-1 groups started per wave as soon as their
     // block columns were final -- removed the idle tail of the sweep and changed nothing: the other workgroup of the CU
     // already fills it.)
-    phase_pt<D, KN>(c, want_grad);
+    if (COOP) {
+        // the parameters of this evaluation for the helpers (drained with the flags in phase_pt, before the phase opens)
+        if (c.tid < D + 2) gst_d(&c.ctl->theta[c.tid], sh->theta[c.tid]);
+    }
+    phase_pt<D, KN, COOP>(c, want_grad);
     if (sh->fail) {
         if (c.tid == 0) { sh->nll = __builtin_inf(); for (int i = 0; i < D + 2; ++i) sh->gth[i] = 0.0; }
         __syncthreads();
         return;
     }
     finish_nll<D, KN>(c);
-    if (want_grad) phase_grad<D, KN>(c);
+    if (want_grad) phase_grad<D, KN, COOP>(c);
+    if (COOP && sh->fail) {          // a wait of the gradient phase gave up
+        if (c.tid == 0) { sh->nll = __builtin_inf(); for (int i = 0; i < D + 2; ++i) sh->gth[i] = 0.0; }
+        __syncthreads();
+        return;
+    }
     if (c.tid == 0) {
         sh->n_eval += 1;
         if (!(sh->nll == sh->nll)) sh->fail = 1;
@@ -1343,6 +1553,145 @@ __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// cooperative tiles: the helper side (gpsat_coop.h).  A workgroup with no tile of its own attaches itself to a running
+// tile (the one with the most work per attached workgroup, same XCD preferred: workgroup ids equal mod 8 share an L2) and
+// takes part in the phases its owner opens -- the bulk queue of the sweep, the group queue of the gradient phase -- with
+// all its waves.  It computes the same scaled coordinates from the same parameters as the owner, reads and writes the
+// owner's workspace, and keeps nothing the owner waits for except its check-in (`active`).
+// ---------------------------------------------------------------------------------------------
+// (the context travels BY VALUE into these functions: a context whose address is taken would live in scratch memory in the
+// kernel's hot loops too)
+template <int D, int KN>
+__device__ __noinline__ f32x2 evaluate_coop(Ctx<D, KN> c, bool want_grad) {
+    evaluate<D, KN, true>(c, want_grad);
+    f32x2 r = {c.sf2, c.sn2};
+    return r;
+}
+
+struct HelpArgs {                // what a helper needs of the kernel arguments
+    void* coop;
+    float* ws;
+    size_t ws_stride;
+    const long long* obs_off;
+    const float* X;
+    int grid;
+};
+
+// hp[0] owner attached to (-1: none)  hp[1] last phase sequence number taken part in  hp[2] tile staged in LDS (-1: none)
+// hp[3] tile of the phase  hp[4] want_m  hp[5] decision of thread 0 for this episode (0: nothing, COOP_SWEEP, COOP_GRAD)
+template <int D, int KN>
+__device__ __noinline__ void helper_episode(Ctx<D, KN> c, const HelpArgs A) {
+    Shared* sh = shared_state();
+    gCoopCtl* ctls = as_gctl(A.coop);
+    const int grid = A.grid;
+    if (c.w == 0) {
+        if (sh->hp[0] < 0) {
+            // scan: lane l looks at the workgroups l, l + 64, ...; key = work per attached workgroup, same-XCD doubled
+            int best = -1;
+            for (int i = c.lane; i < grid; i += 64) {
+                const int sc = __hip_atomic_load(&ctls[i].score, RLX_AGENT);
+                if (sc <= 0 || i == (int)blockIdx.x) continue;
+                const int hl = __hip_atomic_load(&ctls[i].helpers, RLX_AGENT);
+                if (hl >= __hip_atomic_load(&ctls[i].hcap, RLX_AGENT)) continue;
+                int key = (sc * (((i ^ (int)blockIdx.x) & 7) == 0 ? 2 : 1)) / (1 + hl);
+                key = (min(key, 0xffff) << 12) | i;
+                best = max(best, key);
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) best = max(best, __shfl_xor(best, off));
+            if (c.lane == 0 && best >= 0) {
+                const int b = best & 0xfff;
+                const int h = __hip_atomic_fetch_add(&ctls[b].helpers, 1, RLX_AGENT);
+                if (h >= __hip_atomic_load(&ctls[b].hcap, RLX_AGENT)) {
+                    __hip_atomic_fetch_add(&ctls[b].helpers, -1, RLX_AGENT);
+                } else {
+                    sh->hp[0] = b;
+                    sh->hp[1] = -1;           // any open phase may be joined
+                }
+            }
+        }
+        if (c.lane == 0) {
+            int decision = 0;
+            const int b = sh->hp[0];
+            if (b >= 0) {
+                gCoopCtl* ctl = ctls + b;
+                const unsigned wd = __hip_atomic_load(&ctl->phase, RLX_AGENT);
+                const int kind = (int)(wd & 3u), seq = (int)(wd >> 2);
+                if (kind == COOP_RELEASED || __hip_atomic_load(&ctl->score, RLX_AGENT) <= 0) {
+                    __hip_atomic_fetch_add(&ctl->helpers, -1, RLX_AGENT);
+                    sh->hp[0] = -1;
+                } else if ((kind == COOP_SWEEP || kind == COOP_GRAD) && seq != sh->hp[1]) {
+                    __hip_atomic_fetch_add(&ctl->active, 1, RLX_AGENT);
+                    if (__hip_atomic_load(&ctl->phase, RLX_AGENT) != wd) {
+                        __hip_atomic_fetch_add(&ctl->active, -1, RLX_AGENT);       // closed meanwhile: not ours
+                    } else {
+                        decision = kind;
+                        sh->hp[1] = seq;
+                        sh->hp[3] = __hip_atomic_load(&ctl->tile, RLX_AGENT);
+                        sh->hp[4] = __hip_atomic_load(&ctl->want_m, RLX_AGENT);
+                        for (int i = 0; i < D + 2; ++i) sh->theta[i] = gld_d(&ctl->theta[i]);
+                    }
+                }
+            }
+            if (!decision) __builtin_amdgcn_s_sleep(64);
+            sh->hp[5] = decision;
+        }
+    }
+    __syncthreads();
+    const int kind = sh->hp[5];
+    if (kind == 0) return;
+    const int b = sh->hp[0], t = sh->hp[3];
+    const bool want_m = sh->hp[4] != 0;
+    // this workgroup's context becomes the owner's tile
+    c.helper = true;
+    c.ctl = ctls + b;
+    c.ws = A.ws + (size_t)b * A.ws_stride;
+    c.zg = as_gfloat(c.ws + (size_t)(c.zb - 8) * BLK);
+    c.ag = c.zg + 4 * BLK;
+    const long long o0 = A.obs_off[t], o1 = A.obs_off[t + 1];
+    c.N = (int)(o1 - o0);
+    c.P = 0;
+    c.NB = (c.N + 31) / 32;
+    c.Npad = c.NB * 32;
+    c.dT0 = c.NB * c.NB;
+    c.vs0 = c.dT0 + c.NB;
+    c.cv0 = c.vs0 + NW * 2 * c.NB;
+    c.gp0 = c.vs0 * (BLK * 4);
+    if (sh->hp[2] != t) {
+        for (int idx = c.tid; idx < c.Npad; idx += NT) {
+            const bool v = idx < c.N;
+#pragma unroll
+            for (int d = 0; d < D; ++d) lds_f[c.L.xs + d * c.Npad + idx] = v ? A.X[(size_t)(o0 + idx) * D + d] : 0.f;
+        }
+        if (c.tid == 0) sh->hp[2] = t;
+    }
+    __syncthreads();
+    {   // the owner's scaled coordinates: same operations on the same values (evaluate)
+        float invl[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) invl[d] = (float)((double)KScale<KN>::c / sh->theta[d]);
+        c.sf2 = (float)sh->theta[D];
+        c.sn2 = (float)sh->theta[D + 1];
+        for (int idx = c.tid; idx < c.Npad; idx += NT) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) lds_f[c.L.xsc + d * c.Npad + idx] = lds_f[c.L.xs + d * c.Npad + idx] * invl[d];
+        }
+        if (kind == COOP_GRAD)
+            for (int idx = c.tid; idx < c.Npad; idx += NT) lds_f[c.L.alpha + idx] = gld_f(c.ag + idx);
+    }
+    __syncthreads();
+    if (kind == COOP_SWEEP) {
+        if (!pt_bulk_loop<D, KN, true>(c, want_m, true) && c.lane == 0) __hip_atomic_store(&c.ctl->fail, 2, RLX_AGENT);
+    } else {
+        grad_loop<D, KN, true>(c);
+    }
+    coop_drain();
+    __syncthreads();
+    if (c.tid == 0) __hip_atomic_fetch_add(&c.ctl->active, -1, RLX_AGENT);
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
 // the persistent kernel
 // ---------------------------------------------------------------------------------------------
 template <int D, int KN>
@@ -1369,9 +1718,15 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
     off = (off + 3) & ~3;
     c.L.tmp = off; off += 32;
     c.L.piv = off; off += 64;
-    c.ws = A.ws + (size_t)blockIdx.x * A.ws_stride;
+    float* const ws_own = A.ws + (size_t)blockIdx.x * A.ws_stride;
+    c.ws = ws_own;
     c.zb = (int)(A.ws_stride / BLK) - 1;            // last block of the workgroup's workspace: zeros
-    for (int i = c.tid; i < BLK; i += NT) c.ws[(size_t)c.zb * BLK + i] = 0.f;
+    if (c.w == 0) stg(c.ws, c.zb, c.lane, zero16());
+    // cooperative tiles: this workgroup's control block (as an owner); z and alpha of a cooperative evaluation live in
+    // the 8 blocks in front of the zero block
+    const bool coop_on = A.coop != nullptr;
+    gCoopCtl* const ctl_own = as_gctl(A.coop) + blockIdx.x;       // dereferenced only when coop_on
+    if (c.tid == 0) { sh->hp[0] = -1; sh->hp[1] = -1; sh->hp[2] = -1; sh->coop_now = 0; sh->coop_seq = 0; }
     c.prof = sh->prof;
     c.trace = nullptr;
 #ifdef GPSAT_PROFILE
@@ -1397,7 +1752,19 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
             }
         }
         __syncthreads();
-        const int entry = sh->tile;
+        int entry = sh->tile;
+        if (entry == -1 && coop_on && !sliced) {
+            // no tile left for this workgroup: help the tiles that are still running until the last one has finished
+            for (;;) {
+                if (c.tid == 0) sh->hp[6] = __hip_atomic_load(A.coop_live, RLX_AGENT);
+                __syncthreads();
+                if (sh->hp[6] <= 0) break;
+                HelpArgs ha;
+                ha.coop = A.coop; ha.ws = A.ws; ha.ws_stride = A.ws_stride; ha.obs_off = A.obs_off; ha.X = A.X;
+                ha.grid = (int)gridDim.x;
+                helper_episode<D, KN>(c, ha);
+            }
+        }
         if (entry == -1) break;
 #ifdef GPSAT_PROFILE
         if (c.tid == 0) sh->tron = (prof_ntiles == 2);
@@ -1449,8 +1816,15 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
                 }
             }
             if (sliced && c.tid == 0) __hip_atomic_fetch_add(&A.ring_ctl[32], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (coop_on && c.tid == 0) __hip_atomic_fetch_add(A.coop_live, -1, RLX_AGENT);
             continue;
         }
+        // this workgroup owns the tile: its own workspace and control block
+        c.helper = false;
+        c.ws = ws_own;
+        c.ctl = ctl_own;
+        c.zg = as_gfloat(ws_own + (size_t)(c.zb - 8) * BLK);
+        c.ag = c.zg + 4 * BLK;
         // ---- stage tile data into LDS (SoA coordinates), zero padding
         for (int idx = c.tid; idx < c.Npad; idx += NT) {
             const bool v = idx < c.N;
@@ -1490,19 +1864,46 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
             sh->phase = optim ? PH_INIT : PH_FINAL;
             sh->want_grad = optim ? 1 : o.want_grad_out;
         }
+        const bool helpable = coop_on && NB >= A.coop_min_nb;
+        if (c.tid == 0) {
+            sh->hp[2] = -1;                        // the coordinates in LDS are this tile's, not a helped one's
+            if (coop_on) sh->coop_seq = (int)(__hip_atomic_load(&ctl_own->phase, RLX_AGENT) >> 2);
+            if (helpable) {
+                // helpers wanted: at most one per 12 block columns (the bulk queue of a panel has NB / 2 groups), 7 at most
+                __hip_atomic_store(&ctl_own->tile, t, RLX_AGENT);
+                __hip_atomic_store(&ctl_own->hcap, min(7, max(1, NB / 12)), RLX_AGENT);
+                __hip_atomic_store(&ctl_own->phase, ((unsigned)sh->coop_seq << 2) | (unsigned)COOP_CLOSED, RLX_AGENT);
+                __hip_atomic_store(&ctl_own->score, NB, RLX_AGENT);
+            }
+        }
         __syncthreads();
 
-        // ================= evaluate / advance loop (one inlined evaluate call site) =================
+        // ================= evaluate / advance loop (one inlined evaluate call site per mode) =================
         const int seg_evals = sliced ? max(1, A.seg_cost / (NB * NB * NB)) : 0x7fffffff;
         bool suspended = false;
         for (int nseg = 1;; ++nseg) {
-            evaluate<D, KN>(c, sh->want_grad != 0);
+            if (helpable) {
+                // cooperative evaluation when helpers are attached (they may still leave: nothing waits for them)
+                if (c.tid == 0) sh->coop_now = (A.coop_force || __hip_atomic_load(&ctl_own->helpers, RLX_AGENT) > 0) ? 1 : 0;
+                __syncthreads();
+            }
+            if (helpable && sh->coop_now) {
+                const f32x2 sv = evaluate_coop<D, KN>(c, sh->want_grad != 0);
+                c.sf2 = sv[0]; c.sn2 = sv[1];
+            } else {
+                evaluate<D, KN, false>(c, sh->want_grad != 0);
+            }
             if (c.tid == 0) opt_advance(sh, H, o);
             __syncthreads();
             if (sh->phase == PH_EXIT) break;
             // time slice used up while the optimiser goes on (the final evaluation + prediction are never split off:
             // prediction needs this workgroup's factorisation)
             if (nseg >= seg_evals && sh->phase != PH_FINAL) { suspended = true; break; }
+        }
+        if (helpable && c.tid == 0) {
+            // no more cooperative phases from this tile: its helpers look elsewhere (the prediction is the owner's alone)
+            __hip_atomic_store(&ctl_own->score, 0, RLX_AGENT);
+            __hip_atomic_store(&ctl_own->phase, ((unsigned)sh->coop_seq << 2) | (unsigned)COOP_RELEASED, RLX_AGENT);
         }
         if (suspended) {
             unsigned* dst = A.state + (size_t)t * A.state_words;
@@ -1546,6 +1947,7 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
             }
         }
         if (sliced && c.tid == 0) __hip_atomic_fetch_add(&A.ring_ctl[32], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (coop_on && c.tid == 0) __hip_atomic_fetch_add(A.coop_live, -1, RLX_AGENT);
     }
 #ifdef GPSAT_PROFILE
     __syncthreads();
@@ -1572,7 +1974,8 @@ size_t workspace_floats_per_wg(int NBmax, int PCcov) {
     // U/M square + DinvT + per-wave V scratch (2 chunks) [+ V of all chunks for the full covariance, one spare chunk
     // for the odd partner] + one block of zeros
     const size_t cov = PCcov > 0 ? (size_t)(PCcov + 1) * NBmax : 0;
-    return (size_t)BLK * ((size_t)NBmax * NBmax + (size_t)NBmax + (size_t)NW * 2 * NBmax + cov + 1);
+    // ... 8 blocks for z and alpha of a cooperative evaluation (gpsat_coop.h), and the zero block
+    return (size_t)BLK * ((size_t)NBmax * NBmax + (size_t)NBmax + (size_t)NW * 2 * NBmax + cov + 8 + 1);
 }
 
 template <int D, int KN>

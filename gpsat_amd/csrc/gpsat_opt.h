@@ -47,6 +47,9 @@ struct Shared {
     int colrow[GPSAT_PT_MAXNB]; // per block column: panels whose rows are in memory
 #endif
     int gradnext;               // dynamic group queue head of the gradient phase
+    int coop_seq;               // cooperative tiles: phases this workgroup has opened as an owner (not part of a tile's state)
+    int coop_now;               // the running evaluation is cooperative
+    int hp[8];                  // helper bookkeeping (see helper_loop of the fp32 kernels)
 #ifdef GPSAT_PROFILE
     unsigned long long prof[NW * 16];      // diagnostic build: cycle counters per wave and code segment
     int tcnt[NW], tron;                    // event trace (workgroup 0): entries per wave, on/off
