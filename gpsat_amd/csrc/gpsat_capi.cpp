@@ -14,6 +14,8 @@
 #include "gpsat_hip.h"
 #include "gpsat_kernels.h"
 
+#define GPSAT_PT_MAXNB_HOST 100        // colrow[] words in a CoopCtl (gpsat_coop.h: GPSAT_PT_MAXNB)
+
 namespace {
 
 thread_local std::string g_err;
@@ -231,6 +233,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
         coop = coop && std::atoi(e) != 0;
         coop_force = std::atoi(e) == 2;
     }
+    if (const char* e = std::getenv("GPSAT_DEBUG_COOP_XCD")) coop_force |= (std::atoi(e) & 3) << 2;   // developer: 1 same-XCD helpers only, 2 others only
     if (const char* e = std::getenv("GPSAT_DEBUG_COOP_MIN_NB")) coop_min_nb = std::max(2, std::atoi(e));
     if (coop) {
         const int cap = (w8 ? 1 : h->wg_per_cu) * h->num_cu;
@@ -387,10 +390,22 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
 #ifdef GPSAT_PROFILE
     HIP_TRY(hipMemcpyAsync(h->prof_host, h->prof.p, sizeof(h->prof_host), hipMemcpyDeviceToHost, h->stream));
 #endif
+    std::vector<int> coop_host;
+    if (coop && std::getenv("GPSAT_DEBUG_COOP_STATS")) {
+        coop_host.resize((size_t)grid * 256);
+        HIP_TRY(hipMemcpyAsync(coop_host.data(), h->coop.p, (size_t)grid * 1024, hipMemcpyDeviceToHost, h->stream));
+    }
     int unfinished = 0;
     if (seg_cost > 0) HIP_TRY(hipMemcpyAsync(&unfinished, d_ring_ctl + 32, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (!coop_host.empty()) {
+        long long st[8] = {0};
+        for (int g = 0; g < grid; ++g) for (int i = 0; i < 8; ++i) st[i] += coop_host[(size_t)g * 256 + 32 + GPSAT_PT_MAXNB_HOST + i];
+        std::fprintf(stderr, "gpsat coop: grid %d T %d: cooperative evaluations %lld, helper phases %lld, helper groups (sweep) %lld, "
+                             "flag waits given up %lld, owner waits given up %lld, pivot failures %lld, helper unwinds %lld\n",
+                     grid, T, st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
+    }
     if (unfinished != 0) {
         // A queue anomaly (an escape hatch of ring_pop taken: gpsat_ring.h) must not cost the caller the batch: run it again
         // with every tile run to completion from the plain queue (same results: slicing does not change a bit of them).

@@ -42,7 +42,11 @@ struct CoopCtl {                  // 1 KiB per workgroup, zeroed by the host bef
     int ready, g0done;
     int pad1[1];
     int colrow[GPSAT_PT_MAXNB];   // per block column: panels whose rows are in memory
-    int pad2[256 - 32 - GPSAT_PT_MAXNB];
+    // statistics of this workgroup (atomic adds; read by the host when GPSAT_DEBUG_COOP_STATS is set):
+    // 0 cooperative evaluations as owner, 1 phases taken part in as helper, 2 groups run as helper, 3 flag waits that gave
+    // up, 4 owner waits that gave up, 5 evaluations failed by a pivot, 6 helper loops unwound
+    int stat[8];
+    int pad2[256 - 32 - GPSAT_PT_MAXNB - 8];
 };
 static_assert(sizeof(CoopCtl) == 1024, "CoopCtl is one KiB");
 
@@ -53,6 +57,7 @@ __device__ __forceinline__ gfloat* as_gfloat(float* p) { return (gfloat*)p; }
 __device__ __forceinline__ gCoopCtl* as_gctl(void* p) { return (gCoopCtl*)p; }
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define COOP_STAT(ctl, i) __hip_atomic_fetch_add(&(ctl)->stat[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define RLX_WG __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP
 
 // every storing wave, before the flag / counter that announces its stores

@@ -678,6 +678,7 @@ __device__ __forceinline__ bool pt_wait_g(gCoopCtl* ctl, const gint* flag, int v
         if ((++spins & 7) == 0 && __hip_atomic_load(&ctl->fail, RLX_AGENT)) return false;
         if (spins > (1 << 21)) {             // never reached by design (seconds); a lost flag must not hang the GPU
             __hip_atomic_store(&ctl->fail, 2, RLX_AGENT);
+            COOP_STAT(ctl, 3);
             return false;
         }
     }
@@ -724,12 +725,12 @@ __device__ __forceinline__ bool pt_wait_lc(Shared* sh, gCoopCtl* ctl, const int*
         if (COOP) __hip_atomic_store(&c.ctl->field, (v), RLX_AGENT);                      \
         else __hip_atomic_store(&sh->field, (v), RLX_WG);                                 \
     } while (0)
-// before a flag that announces this wave's stores
-#define PT_RELEASE()                                                                      \
-    do {                                                                                  \
-        if (COOP) coop_drain();                                                           \
-        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                       \
-    } while (0)
+// Before a flag that announces this wave's stores: the wave waits until they have completed.  Workspace blocks are stored
+// write-through (sc1) and loaded past L1 (sc1) in every mode, so that a tile's data is coherent whichever workgroups touch
+// it from one evaluation to the next; a write-through store that is still on its way when another wave's load of the same
+// block arrives is NOT ordered before that load, even on the same CU (seen as one wrong tile in 200 000 when the flag was
+// raised behind a workgroup-scope fence only, which waits for nothing on gfx950).
+#define PT_RELEASE() coop_drain()
 
 // D00 += U_k,j0^T U_k,j0, D01 += U_k,j0^T U_k,j1, D11 += U_k,j1^T U_k,j1 and the forward-solve partials for k in [kb, ke)
 template <int D, int KN>
@@ -892,7 +893,7 @@ __device__ __forceinline__ bool pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const
         }
         if (lane == 0) {
             sh->logdet += ls;
-            if (bad) { sh->fail = 1; if (COOP) __hip_atomic_store(&c.ctl->fail, 1, RLX_AGENT); }
+            if (bad) { sh->fail = 1; if (COOP) { __hip_atomic_store(&c.ctl->fail, 1, RLX_AGENT); COOP_STAT(c.ctl, 5); } }
         }
         wave_lds_sync();
         if (want_m) {
@@ -1018,7 +1019,7 @@ __device__ __forceinline__ bool pt_run_group(const Ctx<D, KN>& c, const Panel<D>
             const int e = 2 * g + n;
             if (e < q.nItems) PTS(colrow[pt_item_col(q, e)], sq + 1);
         }
-        if (COOP) { if (queued) __hip_atomic_fetch_add(&c.ctl->done, 1, RLX_AGENT); }
+        if (COOP) { if (queued) __hip_atomic_fetch_add(&c.ctl->done, 1, RLX_AGENT); if (c.helper) COOP_STAT(c.ctl, 2); }
         else __hip_atomic_fetch_add(&sh->gdone[sq & 1], 1, RLX_WG);
     }
     PROF_END(c, 5);
@@ -1078,7 +1079,8 @@ __device__ __forceinline__ bool pt_bulk_loop(const Ctx<D, KN>& c, const bool wan
 __device__ __forceinline__ bool coop_wait_eq(gCoopCtl* ctl, const gint* word, int v) {
     for (int spins = 0; __hip_atomic_load(word, RLX_AGENT) != v; ++spins) {
         __builtin_amdgcn_s_sleep(8);
-        if (spins > (1 << 21) || ((spins & 15) == 15 && word != &ctl->active && __hip_atomic_load(&ctl->fail, RLX_AGENT))) return false;
+        if (spins > (1 << 21)) { COOP_STAT(ctl, 4); return false; }
+        if ((spins & 15) == 15 && word != &ctl->active && __hip_atomic_load(&ctl->fail, RLX_AGENT)) return false;
     }
     return true;
 }
@@ -1124,7 +1126,7 @@ __device__ __forceinline__ void phase_pt(Ctx<D, KN>& c, const bool want_m) {
         for (int idx = c.tid; idx < c.Npad; idx += NT) gst_f(c.ag + idx, 0.f);
         coop_drain();
         __syncthreads();
-        if (c.tid == 0) coop_open(sh, c.ctl, COOP_SWEEP);
+        if (c.tid == 0) { coop_open(sh, c.ctl, COOP_SWEEP); COOP_STAT(c.ctl, 0); }
     }
     __syncthreads();
     bool ok = true;
@@ -1148,7 +1150,7 @@ __device__ __forceinline__ void phase_pt(Ctx<D, KN>& c, const bool want_m) {
                     ok = pt_run_group<D, KN, COOP>(c, q, s - 1, 0, false);
                     if (ok && c.lane == 0) PTS(g0done, s);
                 }
-                if (ok && nGroups > 1) ok = pt_run_group<D, KN, COOP>(c, q, s - 1, 1, false);
+                if (NW < 8 && ok && nGroups > 1) ok = pt_run_group<D, KN, COOP>(c, q, s - 1, 1, false);
             }
             if (ok && s < NP) {
                 // run ahead: k-loop of group 0 of panel s (the columns of the next chain), parked in LDS for that chain
@@ -1175,6 +1177,15 @@ __device__ __forceinline__ void phase_pt(Ctx<D, KN>& c, const bool want_m) {
             }
         }
     }
+    if (NW >= 8 && w == 2) {
+        // 8-wave build: group 1 of every panel (the columns of the chain after next) has a wave of its own, so that the
+        // column wave's run-ahead k-loop of panel s and group 1 of panel s-1 -- both on the path the chains wait for, both
+        // growing with the panel index -- run side by side (one wave doing both bounded a helped 2048-point tile)
+        for (int s = 1; s < NP && ok; ++s) {
+            const Panel<D> q = make_panel<D>(NB, s - 1, want_m);
+            if (((q.nItems + 1) >> 1) > 1) ok = pt_run_group<D, KN, COOP>(c, q, s - 1, 1, false);
+        }
+    }
     ok = pt_bulk_loop<D, KN, COOP>(c, want_m, ok);
     if (COOP && !ok && c.lane == 0) {
         // a wave of the owner unwinds: everybody else must, too
@@ -1182,6 +1193,7 @@ __device__ __forceinline__ void phase_pt(Ctx<D, KN>& c, const bool want_m) {
         __hip_atomic_store(&c.ctl->fail, 2, RLX_AGENT);
     }
     TRACE(c, 60, 0);
+    coop_drain();                     // the blocks this wave stored are read by other waves behind the barrier
     __syncthreads();
     if (COOP) {
         // the helpers' groups are part of this sweep: all queue groups done, phase closed, helpers out; then alpha (and a
@@ -1509,6 +1521,7 @@ __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const float* __restr
     }
     if (fcov) {
         // f*_cov = K_** - V^T V by 32 x 32 blocks (p <= q, mirrored), gpflow_models.py:245-263 (predict_f full_cov)
+        coop_drain();                 // V blocks of other waves
         __syncthreads();
         int idx = 0;
         for (int p = 0; p < PC; ++p) {
@@ -1575,6 +1588,7 @@ struct HelpArgs {                // what a helper needs of the kernel arguments
     const long long* obs_off;
     const float* X;
     int grid;
+    int xcd_mode;                // developer: 0 any owner, 1 owners of this workgroup's XCD group only, 2 other groups only
 };
 
 // hp[0] owner attached to (-1: none)  hp[1] last phase sequence number taken part in  hp[2] tile staged in LDS (-1: none)
@@ -1591,6 +1605,8 @@ __device__ __noinline__ void helper_episode(Ctx<D, KN> c, const HelpArgs A) {
             for (int i = c.lane; i < grid; i += 64) {
                 const int sc = __hip_atomic_load(&ctls[i].score, RLX_AGENT);
                 if (sc <= 0 || i == (int)blockIdx.x) continue;
+                if (A.xcd_mode == 1 && ((i ^ (int)blockIdx.x) & 7) != 0) continue;
+                if (A.xcd_mode == 2 && ((i ^ (int)blockIdx.x) & 7) == 0) continue;
                 const int hl = __hip_atomic_load(&ctls[i].helpers, RLX_AGENT);
                 if (hl >= __hip_atomic_load(&ctls[i].hcap, RLX_AGENT)) continue;
                 int key = (sc * (((i ^ (int)blockIdx.x) & 7) == 0 ? 2 : 1)) / (1 + hl);
@@ -1657,7 +1673,9 @@ __device__ __noinline__ void helper_episode(Ctx<D, KN> c, const HelpArgs A) {
     c.vs0 = c.dT0 + c.NB;
     c.cv0 = c.vs0 + NW * 2 * c.NB;
     c.gp0 = c.vs0 * (BLK * 4);
-    if (sh->hp[2] != t) {
+    const bool restage = sh->hp[2] != t;          // every thread reads the marker ...
+    __syncthreads();                              // ... before thread 0 moves it
+    if (restage) {
         for (int idx = c.tid; idx < c.Npad; idx += NT) {
             const bool v = idx < c.N;
 #pragma unroll
@@ -1680,8 +1698,12 @@ __device__ __noinline__ void helper_episode(Ctx<D, KN> c, const HelpArgs A) {
             for (int idx = c.tid; idx < c.Npad; idx += NT) lds_f[c.L.alpha + idx] = gld_f(c.ag + idx);
     }
     __syncthreads();
+    if (c.tid == 0) COOP_STAT(ctls + blockIdx.x, 1);
     if (kind == COOP_SWEEP) {
-        if (!pt_bulk_loop<D, KN, true>(c, want_m, true) && c.lane == 0) __hip_atomic_store(&c.ctl->fail, 2, RLX_AGENT);
+        if (!pt_bulk_loop<D, KN, true>(c, want_m, true) && c.lane == 0) {
+            __hip_atomic_store(&c.ctl->fail, 2, RLX_AGENT);
+            COOP_STAT(ctls + blockIdx.x, 6);
+        }
     } else {
         grad_loop<D, KN, true>(c);
     }
@@ -1721,7 +1743,7 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
     float* const ws_own = A.ws + (size_t)blockIdx.x * A.ws_stride;
     c.ws = ws_own;
     c.zb = (int)(A.ws_stride / BLK) - 1;            // last block of the workgroup's workspace: zeros
-    if (c.w == 0) stg(c.ws, c.zb, c.lane, zero16());
+    if (c.w == 0) { stg(c.ws, c.zb, c.lane, zero16()); coop_drain(); }     // (read behind the barrier at the top of the tile loop)
     // cooperative tiles: this workgroup's control block (as an owner); z and alpha of a cooperative evaluation live in
     // the 8 blocks in front of the zero block
     const bool coop_on = A.coop != nullptr;
@@ -1762,6 +1784,7 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
                 HelpArgs ha;
                 ha.coop = A.coop; ha.ws = A.ws; ha.ws_stride = A.ws_stride; ha.obs_off = A.obs_off; ha.X = A.X;
                 ha.grid = (int)gridDim.x;
+                ha.xcd_mode = (A.coop_force >> 2) & 3;
                 helper_episode<D, KN>(c, ha);
             }
         }
@@ -1884,7 +1907,7 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
         for (int nseg = 1;; ++nseg) {
             if (helpable) {
                 // cooperative evaluation when helpers are attached (they may still leave: nothing waits for them)
-                if (c.tid == 0) sh->coop_now = (A.coop_force || __hip_atomic_load(&ctl_own->helpers, RLX_AGENT) > 0) ? 1 : 0;
+                if (c.tid == 0) sh->coop_now = ((A.coop_force & 1) || __hip_atomic_load(&ctl_own->helpers, RLX_AGENT) > 0) ? 1 : 0;
                 __syncthreads();
             }
             if (helpable && sh->coop_now) {
