@@ -227,7 +227,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     // cooperative tiles (fp32 kernels): a workgroup without a tile helps a running one (gpsat_coop.h).  With fewer tiles than
     // resident workgroups the launch is widened by the helpers the large tiles can use.
     bool coop = !f64;
-    int coop_min_nb = 12;
+    int coop_min_nb = 12, coop_hdiv = 12;
     int coop_force = 0;
     if (const char* e = std::getenv("GPSAT_DEBUG_COOP")) {           // developer: 0 = off, 2 = cooperative code path always
         coop = coop && std::atoi(e) != 0;
@@ -235,12 +235,18 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     }
     if (const char* e = std::getenv("GPSAT_DEBUG_COOP_XCD")) coop_force |= (std::atoi(e) & 3) << 2;   // developer: 1 same-XCD helpers only, 2 others only
     if (const char* e = std::getenv("GPSAT_DEBUG_COOP_MIN_NB")) coop_min_nb = std::max(2, std::atoi(e));
+    if (const char* e = std::getenv("GPSAT_DEBUG_COOP_HDIV")) coop_hdiv = std::max(1, std::atoi(e));
+    // Helpers must be capacity that would otherwise idle.  8-wave build: one workgroup per CU, a workgroup without a tile
+    // leaves its CU empty -- always on.  4-wave build (two workgroups per CU): an idle workgroup's CU-mate already runs 1.4 x
+    // faster alone, and a helper takes that back (measured on BASELINE configs[1]: the helped tail is 2 % SLOWER) -- on only
+    // while the launch has fewer tiles than CUs, widened to at most one workgroup per CU.
+    if (coop && !w8 && T >= h->num_cu) coop = false;
     if (coop) {
-        const int cap = (w8 ? 1 : h->wg_per_cu) * h->num_cu;
+        const int cap = h->num_cu;
         long long want = grid;
         for (int t = 0; t < T && want < cap; ++t) {
             const int nb = (int)((b->obs_off[t + 1] - b->obs_off[t] + bs - 1) / bs);
-            if (nb >= coop_min_nb) want += std::min(7, std::max(1, nb / 12));
+            if (nb >= coop_min_nb) want += std::min(7, std::max(1, nb / coop_hdiv));
         }
         if (T < cap) grid = (int)std::min<long long>(cap, want);
     }
@@ -326,7 +332,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     }
 
     gpsat::KernelArgs a;
-    a.coop = nullptr; a.coop_live = nullptr; a.coop_min_nb = coop_min_nb; a.coop_force = coop_force;
+    a.coop = nullptr; a.coop_live = nullptr; a.coop_min_nb = coop_min_nb; a.coop_hdiv = coop_hdiv; a.coop_force = coop_force;
     if (coop) {
         // [grid] control blocks of 1 KiB, zeroed every launch, then the count of unfinished tiles
         const size_t cb = (size_t)grid * 1024;

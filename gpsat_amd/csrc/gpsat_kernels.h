@@ -49,6 +49,7 @@ struct KernelArgs {
     void* coop;                   // [grid] CoopCtl
     int* coop_live;               // tiles not finished yet (preset T): the helpers' exit condition
     int coop_min_nb;              // smallest tile (block columns) worth helping
+    int coop_hdiv;                // helpers wanted per tile: NB / coop_hdiv (1..7)
     int coop_force;               // developer / tests: every evaluation of a helpable tile runs the cooperative code path, helped or not
 };
 

@@ -1765,7 +1765,21 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
     const bool sliced = A.seg_cost > 0;
     for (;;) {
         __syncthreads();
-        if (c.tid == 0) {
+        HelpArgs ha;
+        ha.coop = A.coop; ha.ws = A.ws; ha.ws_stride = A.ws_stride; ha.obs_off = A.obs_off; ha.X = A.X;
+        ha.grid = (int)gridDim.x;
+        ha.xcd_mode = (A.coop_force >> 2) & 3;
+        if (sliced && coop_on) {
+            // claim a ring slot; while it is empty (the tail of the batch: fewer unfinished tiles than workgroups) help a
+            // running tile instead of spinning
+            if (c.tid == 0) sh->hp[7] = (int)ring_claim(A);
+            for (int spins = 0;; ++spins) {
+                if (c.tid == 0) sh->tile = (spins > (1 << 22)) ? -1 : ring_look(A, (unsigned)sh->hp[7]);
+                __syncthreads();
+                if (sh->tile != -2) break;
+                helper_episode<D, KN>(c, ha);
+            }
+        } else if (c.tid == 0) {
             if (sliced) {
                 sh->tile = ring_pop(A);
             } else {
@@ -1781,10 +1795,6 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
                 if (c.tid == 0) sh->hp[6] = __hip_atomic_load(A.coop_live, RLX_AGENT);
                 __syncthreads();
                 if (sh->hp[6] <= 0) break;
-                HelpArgs ha;
-                ha.coop = A.coop; ha.ws = A.ws; ha.ws_stride = A.ws_stride; ha.obs_off = A.obs_off; ha.X = A.X;
-                ha.grid = (int)gridDim.x;
-                ha.xcd_mode = (A.coop_force >> 2) & 3;
                 helper_episode<D, KN>(c, ha);
             }
         }
@@ -1842,7 +1852,12 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
             if (coop_on && c.tid == 0) __hip_atomic_fetch_add(A.coop_live, -1, RLX_AGENT);
             continue;
         }
-        // this workgroup owns the tile: its own workspace and control block
+        // this workgroup owns the tile: its own workspace and control block (it may have helped another tile while it
+        // waited for this one: it lets go of it)
+        if (coop_on && c.tid == 0 && sh->hp[0] >= 0) {
+            __hip_atomic_fetch_add(&(as_gctl(A.coop) + sh->hp[0])->helpers, -1, RLX_AGENT);
+            sh->hp[0] = -1;
+        }
         c.helper = false;
         c.ws = ws_own;
         c.ctl = ctl_own;
@@ -1892,9 +1907,9 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
             sh->hp[2] = -1;                        // the coordinates in LDS are this tile's, not a helped one's
             if (coop_on) sh->coop_seq = (int)(__hip_atomic_load(&ctl_own->phase, RLX_AGENT) >> 2);
             if (helpable) {
-                // helpers wanted: at most one per 12 block columns (the bulk queue of a panel has NB / 2 groups), 7 at most
+                // helpers wanted: one per coop_hdiv block columns (the bulk queue of a panel has NB / 2 groups), 7 at most
                 __hip_atomic_store(&ctl_own->tile, t, RLX_AGENT);
-                __hip_atomic_store(&ctl_own->hcap, min(7, max(1, NB / 12)), RLX_AGENT);
+                __hip_atomic_store(&ctl_own->hcap, min(7, max(1, NB / A.coop_hdiv)), RLX_AGENT);
                 __hip_atomic_store(&ctl_own->phase, ((unsigned)sh->coop_seq << 2) | (unsigned)COOP_CLOSED, RLX_AGENT);
                 __hip_atomic_store(&ctl_own->score, NB, RLX_AGENT);
             }
@@ -1921,7 +1936,13 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
             if (sh->phase == PH_EXIT) break;
             // time slice used up while the optimiser goes on (the final evaluation + prediction are never split off:
             // prediction needs this workgroup's factorisation)
-            if (nseg >= seg_evals && sh->phase != PH_FINAL) { suspended = true; break; }
+            if (nseg >= seg_evals && sh->phase != PH_FINAL) {
+                // ... unless no other tile is waiting in the ring: the slice would only hand this tile to a workgroup that
+                // waits for work (state through device memory for nothing) and shake off the tile's helpers
+                if (c.tid == 0) sh->hp[6] = ring_waiting_tiles(A);
+                __syncthreads();
+                if (sh->hp[6] > 0) { suspended = true; break; }
+            }
         }
         if (helpable && c.tid == 0) {
             // no more cooperative phases from this tile: its helpers look elsewhere (the prediction is the owner's alone)

@@ -28,6 +28,27 @@ static __device__ __forceinline__ int ring_pop(const KernelArgs& A) {
     }
 }
 
+// The two halves of ring_pop for a workgroup that does something else while its slot is empty (cooperative tiles: it
+// helps a running tile): claim a slot once, then look at it.  ring_look: the entry, -1 when every tile is finished,
+// -2 when the slot is still empty.
+static __device__ __forceinline__ unsigned ring_claim(const KernelArgs& A) {
+    return (unsigned)__hip_atomic_fetch_add(&A.ring_ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+static __device__ __forceinline__ int ring_look(const KernelArgs& A, unsigned s) {
+    const unsigned long long v = __hip_atomic_load(A.ring + (s & (unsigned)A.ring_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(v >> 32) == s + 1u) return (int)(unsigned)v;
+    if (__hip_atomic_load(&A.ring_ctl[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) return -1;
+    return -2;
+}
+
+// entries pushed and not yet claimed (<= 0: whoever pops next waits): a tile that would be suspended now would only move to
+// a workgroup that is waiting for it -- it may as well keep running where it is
+static __device__ __forceinline__ int ring_waiting_tiles(const KernelArgs& A) {
+    return __hip_atomic_load(&A.ring_ctl[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+           __hip_atomic_load(&A.ring_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 static __device__ __forceinline__ void ring_push(const KernelArgs& A, int tile) {
     const unsigned s = (unsigned)__hip_atomic_fetch_add(&A.ring_ctl[16], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long v = ((unsigned long long)(s + 1u) << 32) | 0x80000000ull | (unsigned)tile;
