@@ -62,6 +62,7 @@ struct gpsat_handle {
     char name[256] = {0};
     double last_kernel_ms = 0.0, last_total_ms = 0.0;
     bool force_unsliced = false;       // retry of a batch whose time-sliced queue ended with unfinished tiles
+    bool force_solo = false;           // retry of a batch in which a team barrier gave up
     // device buffers (grown lazily, owned by the handle)
     DevBuf meta_i64, meta_f64, meta_misc, out_f64, out_i32, bulk_in, bulk_out, ws, prof, ring, state, coop;
     DevBuf sel_pts, sel_refs, sel_cnt, sel_idx, sel_box;
@@ -224,6 +225,12 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
                             : (w8 ? gpsat::shared_bytes_w8(D, NBmax) : gpsat::shared_bytes(D, NBmax));
     if (smem > 160 * 1024) return fail(GPSAT_EINVAL, "tile too large for LDS");
     if (w8 || (f64 && !d4)) grid = std::min(grid, h->num_cu);
+    // teams (fp64 kernels, 8-wave build): with few large tiles, G workgroups run every tile together (gpsat_kernels_f64.hip)
+    int team = 1;
+    if (f64 && !d4 && NBmax >= 64 && 2 * T <= h->num_cu) team = std::min(16, h->num_cu / T);
+    if (const char* e = std::getenv("GPSAT_DEBUG_TEAM")) { if (f64 && !d4) team = std::max(1, std::min(32, std::atoi(e))); }
+    if (h->force_solo) team = 1;
+    if (team > 1) grid = std::min(T, std::max(1, h->num_cu / team)) * team;
     // cooperative tiles (fp32 kernels): a workgroup without a tile helps a running one (gpsat_coop.h).  With fewer tiles than
     // resident workgroups the launch is widened by the helpers the large tiles can use.
     bool coop = !f64;
@@ -251,7 +258,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
         if (T < cap) grid = (int)std::min<long long>(cap, want);
     }
     if (const char* e = std::getenv("GPSAT_DEBUG_GRID")) grid = std::max(1, std::min(grid, std::atoi(e)));   // developer: fewer resident workgroups
-    if ((rc = h->ws.reserve((size_t)grid * wsf * esz))) return rc;
+    if ((rc = h->ws.reserve((size_t)(grid / team) * wsf * esz))) return rc;      // one workspace per workgroup, or per team
 
     const char *dX = nullptr, *dy = nullptr, *dXs = nullptr;
     char *dfm = nullptr, *dfv = nullptr, *dyv = nullptr, *dcov = nullptr;
@@ -308,7 +315,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
         if (T > grid && max_cost * 4.0 * grid <= sum_cost && tiles_per_wg <= 64.0) seg_cost = 4 * (512 / bs) * (512 / bs) * (512 / bs);
         // developer / tests: slice length in NB^3 units (0 = off, 1 = every evaluation), whatever the batch looks like
         if (const char* e = std::getenv("GPSAT_DEBUG_SEG")) seg_cost = std::max(0, std::atoi(e));
-        if (h->force_unsliced) seg_cost = 0;
+        if (h->force_unsliced || team > 1) seg_cost = 0;
     }
     unsigned long long* d_ring = nullptr; int* d_ring_ctl = nullptr; unsigned* d_state = nullptr;
     int ring_mask = 0;
@@ -341,6 +348,13 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
         HIP_TRY(hipMemcpyAsync(static_cast<char*>(h->coop.p) + cb, &b->T, sizeof(int), hipMemcpyHostToDevice, h->stream));
         a.coop = h->coop.p;
         a.coop_live = reinterpret_cast<int*>(static_cast<char*>(h->coop.p) + cb);
+    }
+    a.team_size = team; a.team_ctl = nullptr;
+    if (team > 1) {
+        const size_t tb = (size_t)(grid / team) * 256;
+        if ((rc = h->coop.reserve(tb))) return rc;
+        HIP_TRY(hipMemsetAsync(h->coop.p, 0, tb, h->stream));
+        a.team_ctl = h->coop.p;
     }
     a.ring = d_ring; a.ring_ctl = d_ring_ctl; a.state = d_state; a.ring_mask = ring_mask; a.state_words = state_words; a.seg_cost = seg_cost;
     a.T = T; a.kernel = b->kernel; a.optimiser = b->optimiser; a.max_iter = b->max_iter;
@@ -396,6 +410,11 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
 #ifdef GPSAT_PROFILE
     HIP_TRY(hipMemcpyAsync(h->prof_host, h->prof.p, sizeof(h->prof_host), hipMemcpyDeviceToHost, h->stream));
 #endif
+    std::vector<int> team_host;
+    if (team > 1) {
+        team_host.resize((size_t)(grid / team) * 64);
+        HIP_TRY(hipMemcpyAsync(team_host.data(), h->coop.p, team_host.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    }
     std::vector<int> coop_host;
     if (coop && std::getenv("GPSAT_DEBUG_COOP_STATS")) {
         coop_host.resize((size_t)grid * 256);
@@ -411,6 +430,18 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
         std::fprintf(stderr, "gpsat coop: grid %d T %d: cooperative evaluations %lld, helper phases %lld, helper groups (sweep) %lld, "
                              "flag waits given up %lld, owner waits given up %lld, pivot failures %lld, helper unwinds %lld\n",
                      grid, T, st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
+    }
+    if (!team_host.empty() && std::getenv("GPSAT_DEBUG_TEAM_STATS"))
+        std::fprintf(stderr, "gpsat team 0 (size %d), factorisation, owner thread 0, s_memtime ticks: own work of (A) %d, (A) wait + barrier %d, (B) + barrier %d, "
+                             "(C) + barrier %d\n", team, team_host[24], team_host[25], team_host[26], team_host[27]);
+    for (size_t g = 0; g < team_host.size() / 64; ++g) {
+        if (team_host[g * 64 + 5]) {          // TeamCtl::timeout: a team barrier gave up (never by design) -- run the batch again, one workgroup per tile
+            std::fprintf(stderr, "gpsat: a team barrier gave up; re-running the batch with one workgroup per tile\n");
+            h->force_solo = true;
+            const int rc2 = gpsat_fit_predict_batch(h, b);
+            h->force_solo = false;
+            return rc2;
+        }
     }
     if (unfinished != 0) {
         // A queue anomaly (an escape hatch of ring_pop taken: gpsat_ring.h) must not cost the caller the batch: run it again

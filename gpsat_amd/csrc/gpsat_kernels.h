@@ -48,6 +48,10 @@ struct KernelArgs {
     // find no tile left attach themselves to a running tile and pull groups of its sweep / gradient queues
     void* coop;                   // [grid] CoopCtl
     int* coop_live;               // tiles not finished yet (preset T): the helpers' exit condition
+    // teams (fp64 kernels, gpsat_kernels_f64.hip): team_size workgroups run one tile together; [grid / team_size] TeamCtl of
+    // 256 bytes, zeroed before the launch
+    int team_size;
+    void* team_ctl;
     int coop_min_nb;              // smallest tile (block columns) worth helping
     int coop_hdiv;                // helpers wanted per tile: NB / coop_hdiv (1..7)
     int coop_force;               // developer / tests: every evaluation of a helpable tile runs the cooperative code path, helped or not

@@ -1499,6 +1499,9 @@ __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const float* __restr
             f32x16 Vb = zero16();
             mma_blk(Vb, Lop, Wb);
             stg(c.ws, v0 + NB + j, lane, Vb);
+            // this wave loads these V blocks again in its next steps: a write-through store still on its way is not ordered
+            // before a load of the same bytes, not even from the same wave (seen in the fp64 team kernel)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float zr = lds_f[c.L.z + 32 * j + rho(r, c.h)];

@@ -49,19 +49,43 @@ constexpr int BLK = 256;       // doubles per block
 
 __device__ __forceinline__ int rowof(int r, int q) { return q + 4 * r; }
 
-__device__ __forceinline__ f64x4 ldg(const double* __restrict__ ws, int blk, int lane) {
+// Workspace blocks.  A tile run by ONE workgroup moves them with plain global loads / stores (the CU's own L1 / L2 serve
+// them).  A tile run by a TEAM of workgroups (below) moves them device-coherently: buffer_load / buffer_store ... sc1
+// (write-through, past L1), every hand-over behind a drain -- MI355X_MICROARCH.md, "inter-workgroup visibility".  A tile is
+// run in one mode from its first to its last evaluation, so the two kinds of access never meet on the same bytes.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <bool TEAM>
+__device__ __forceinline__ f64x4 ldg_t(const double* __restrict__ ws, int blk, int lane) {
+    if (TEAM) {
+        __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(ws), 0, 0x7fffffff, 0x00020000);
+        const int so = blk * (BLK * 8), vo = lane * 32;
+        const f64x2 a = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 16));
+        const f64x2 b = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r, vo + 16, so, 16));
+        f64x4 v = {a[0], a[1], b[0], b[1]};
+        return v;
+    }
     const f64x2* p = reinterpret_cast<const f64x2*>(ws + (size_t)blk * BLK + lane * 4);
     const f64x2 a = p[0], b = p[1];
     f64x4 v = {a[0], a[1], b[0], b[1]};
     return v;
 }
 
-__device__ __forceinline__ void stg(double* __restrict__ ws, int blk, int lane, const f64x4& v) {
-    f64x2* p = reinterpret_cast<f64x2*>(ws + (size_t)blk * BLK + lane * 4);
+template <bool TEAM>
+__device__ __forceinline__ void stg_t(double* __restrict__ ws, int blk, int lane, const f64x4& v) {
     f64x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    if (TEAM) {
+        __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(ws, 0, 0x7fffffff, 0x00020000);
+        const int so = blk * (BLK * 8), vo = lane * 32;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), r, vo, so, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, b), r, vo + 16, so, 16);
+        return;
+    }
+    f64x2* p = reinterpret_cast<f64x2*>(ws + (size_t)blk * BLK + lane * 4);
     p[0] = a;
     p[1] = b;
 }
+#define ldg ldg_t<TEAM>
+#define stg stg_t<TEAM>
 
 __device__ __forceinline__ f64x4 ldl(int off, int lane) {
     const f64x2* p = reinterpret_cast<const f64x2*>(lds_d + off + lane * 4);
@@ -121,6 +145,41 @@ __device__ __forceinline__ void kfun(double r2, double& kf, double& gg) {
 
 struct Lay { int xsc, y, z, alpha, Ad, LT, tmp, Pn, tp4; };   // double offsets into lds_d
 
+// ---------------------------------------------------------------------------------------------
+// Teams (large fp64 tiles): G workgroups run ONE tile together, bulk-synchronously -- the kernel's phases as they are, every
+// workgroup barrier between them replaced by a team barrier in device memory, the loops over block columns dealt over the
+// team's G * NW waves, and what the waves of one workgroup exchange through LDS (the panel's diagonal region, z, alpha)
+// exchanged through the workspace of member 0 instead.  Member 0 (the owner) runs the optimiser, the serial part of every
+// panel and the prediction; the others follow its commands.  The team is fixed by the host for the whole launch
+// (KernelArgs::team_size), so a tile's workspace is only ever touched device-coherently (ldg_t<true> / stg_t<true>).
+// Per item the arithmetic is what one workgroup does, per-column updates of alpha keep their order (one writer per column
+// and panel, panels separated by team barriers), the gradient's partial sums are added in a fixed order: a team returns the
+// bits one workgroup returns.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) int gint;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) double gdouble;
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+enum { TEAM_EVAL = 1, TEAM_TILE = 2, TEAM_EXIT = 3 };
+
+struct TeamCtl {                 // 256 B per team, zeroed by the host before the launch; agent-scope atomics only
+    int bar;                     // team barrier: arrivals so far (monotone)
+    int fail;                    // the running evaluation has failed (owner, before the barrier that follows the serial part)
+    int cmd;                     // owner -> members, read behind the command barrier
+    int tile;
+    int want_grad;
+    int timeout;                 // a barrier gave up (never by design)
+    int pad0[2];
+    double theta[8];
+    int pad1[40];
+};
+static_assert(sizeof(TeamCtl) == 256, "TeamCtl is 256 bytes");
+typedef __attribute__((address_space(1))) TeamCtl gTeamCtl;
+
+__device__ __forceinline__ double gld_d(const gdouble* p) { return __longlong_as_double((long long)__hip_atomic_load((const gu64*)p, RLX_AGENT)); }
+__device__ __forceinline__ void gst_d(gdouble* p, double v) { __hip_atomic_store((gu64*)p, (unsigned long long)__double_as_longlong(v), RLX_AGENT); }
+
 template <int D, int KN>
 struct Ctx {
     Lay L;
@@ -129,7 +188,38 @@ struct Ctx {
     int N, NB, Npad, P;
     int tid, lane, w, q, g;
     double sf2, sn2;
+    // team: this wave's index among the team's G * NW waves, their number, the team's control block, and the exchange areas
+    // in the owner's workspace (panel diagonal region 10 blocks + 64 doubles, z, alpha, the gradient's partial sums)
+    int vw, nwt, member, G;
+    gTeamCtl* tc;
+    int pn0;                     // block index of the exchanged diagonal region
+    gdouble *tpg, *zg, *ag;
+    int gp0;                     // byte offset of the gradient phase's per-item partial sums (aliases the prediction scratch)
 };
+
+// Every wave has drained its stores, every workgroup of the team has arrived: data stored sc1 before the barrier is read
+// (sc1) behind it by any member.  One workgroup (G == 1): a plain workgroup barrier.  A barrier that gives up (never by
+// design; bounded so that a lost workgroup cannot hang the GPU) marks the evaluation failed.
+template <bool TEAM, int D, int KN>
+__device__ __forceinline__ void team_barrier(Ctx<D, KN>& c) {
+    if (!TEAM) { __syncthreads(); return; }
+    Shared* sh = reinterpret_cast<Shared*>(lds_d);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (c.tid == 0) {
+        sh->hp[0] += 1;                                       // barriers passed by this workgroup
+        const int target = sh->hp[0] * c.G;
+        __hip_atomic_fetch_add(&c.tc->bar, 1, RLX_AGENT);
+        for (int spins = 0; __hip_atomic_load(&c.tc->bar, RLX_AGENT) < target; ++spins) {
+            __builtin_amdgcn_s_sleep(4);
+            if (spins > (1 << 23) || ((spins & 255) == 255 && __hip_atomic_load(&c.tc->timeout, RLX_AGENT))) {
+                __hip_atomic_store(&c.tc->timeout, 1, RLX_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
 
 template <int D, int KN>
 __device__ __forceinline__ f64x4 kblock(const Ctx<D, KN>& c, int bi, int bj) {
@@ -257,16 +347,18 @@ __device__ __forceinline__ void diag_factor(const f64x4& W, int Ad, int lane, f6
 constexpr int PR = 4;
 __device__ __forceinline__ constexpr int pidx(int r, int r2) { return r * PR - (r * (r - 1)) / 2 + (r2 - r); }   // r <= r2 < 4
 
-template <int D, int KN>
+template <int D, int KN, bool TEAM>
 __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
     Shared* sh = reinterpret_cast<Shared*>(lds_d);
     const int NB = c.NB, lane = c.lane, w = c.w;
     if (c.tid == 0) { sh->logdet = 0.0; sh->fail = 0; }
     __syncthreads();
+    unsigned long long tA = 0, tB = 0, tC = 0, tW = 0, t0 = 0;
     for (int j0 = 0; j0 < NB; j0 += PR) {
         const int nr = min(PR, NB - j0);
+        if (TEAM) t0 = __builtin_amdgcn_s_memtime();
         // ---- (A) diagonal region: D_rr' = K_jr,jr' - sum_{k<j0} U_k,jr^T U_k,jr'  and  t_r = sum_{k<j0} U_k,jr^T z_k
-        for (int bb = w; bb < 10; bb += NW) {
+        for (int bb = c.vw; bb < 10; bb += c.nwt) {
             int r = 0, r2 = bb;
             if (bb >= 9) { r = 3; r2 = 3; } else if (bb >= 7) { r = 2; r2 = bb - 5; } else if (bb >= 4) { r = 1; r2 = bb - 3; }
             if (r2 >= nr) continue;
@@ -274,34 +366,55 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
             f64x4 acc = zero4();
             double tp = 0.0;
             if (j0 > 0) {
-                f64x4 A = ldg(c.ws, j0 + r, lane), B = ldg(c.ws, j0 + r2, lane);
-                for (int k = 0; k < j0; ++k) {
-                    f64x4 nA = A, nB = B;
-                    if (k + 1 < j0) {
-                        nA = ldg(c.ws, (k + 1) * NB + j0 + r, lane);
-                        nB = ldg(c.ws, (k + 1) * NB + j0 + r2, lane);
-                    }
-                    mma_blk(acc, A, B);
-                    if (dg) {
+                // One product per step: the loop runs at the latency of its loads unless several steps are in flight.  A ring
+                // of PF operand pairs (the tail reloads the last pair, unused) keeps PF steps of loads outstanding; the
+                // products are issued in the same order as ever.  (With one step in flight this phase -- ten chains per panel,
+                // everybody else waiting -- was 6 of the 16 ms a team could not shorten in an N = 2500 evaluation.)
+                constexpr int PF = 6;
+                f64x4 Ar[PF], Br[PF];
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) tp = fma(A[rr], lds_d[c.L.z + BS * k + rowof(rr, c.q)], tp);
+                for (int u = 0; u < PF; ++u) {
+                    const int kk = min(u, j0 - 1);
+                    Ar[u] = ldg(c.ws, kk * NB + j0 + r, lane);
+                    Br[u] = ldg(c.ws, kk * NB + j0 + r2, lane);
+                }
+                for (int k0 = 0; k0 < j0; k0 += PF) {
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) {
+                        const int k = k0 + u;
+                        if (k < j0) {
+                            mma_blk(acc, Ar[u], Br[u]);
+                            if (dg) {
+#pragma unroll
+                                for (int rr = 0; rr < 4; ++rr) tp = fma(Ar[u][rr], lds_d[c.L.z + BS * k + rowof(rr, c.q)], tp);
+                            }
+                            const int kn = min(k + PF, j0 - 1);
+                            Ar[u] = ldg(c.ws, kn * NB + j0 + r, lane);
+                            Br[u] = ldg(c.ws, kn * NB + j0 + r2, lane);
+                        }
                     }
-                    A = nA; B = nB;
                 }
             }
             acc = kblock<D, KN>(c, j0 + r, j0 + r2) - acc;
-            stl(c.L.Pn + bb * BLK, lane, acc);
+            if (TEAM) stg(c.ws, c.pn0 + bb, lane, acc);
+            else stl(c.L.Pn + bb * BLK, lane, acc);
             if (dg) {
                 const double t = qsum(tp);
-                if (c.q == 0) lds_d[c.L.tp4 + BS * r + c.g] = t;
+                if (c.q == 0) {
+                    if (TEAM) gst_d(c.tpg + BS * r + c.g, t);
+                    else lds_d[c.L.tp4 + BS * r + c.g] = t;
+                }
             }
         }
-        __syncthreads();
-        // ---- (B) the 4 x 4 block triangle (wave 0): after it slot (r,r) of Pn holds (L_r^-1)^T, slot (r,r') holds U_jr,jr'
-        if (w == 0) {
+        if (TEAM) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tW += t1 - t0; t0 = t1; }
+        team_barrier<TEAM>(c);
+        if (TEAM) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tA += t1 - t0; t0 = t1; }
+        // ---- (B) the 4 x 4 block triangle (wave 0 of the owner): after it slot (r,r) of Pn holds (L_r^-1)^T, slot (r,r')
+        // holds U_jr,jr'
+        if (w == 0 && c.member == 0) {
             f64x4 Dd[10];
 #pragma unroll
-            for (int bb = 0; bb < 10; ++bb) Dd[bb] = ldl(c.L.Pn + bb * BLK, lane);
+            for (int bb = 0; bb < 10; ++bb) Dd[bb] = TEAM ? ldg(c.ws, c.pn0 + bb, lane) : ldl(c.L.Pn + bb * BLK, lane);
             double tpx[PR] = {0.0, 0.0, 0.0, 0.0};      // per-lane partials of t_r' from the rows of this panel
 #pragma unroll
             for (int r = 0; r < PR; ++r) {
@@ -314,15 +427,22 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
                     stg(c.ws, jr * NB + jr, lane, S1);
                     stg(c.ws, c.dT0 + jr, lane, S2);
                     stl(c.L.Pn + pidx(r, r) * BLK, lane, S2);
-                    const double t = lds_d[c.L.tp4 + BS * r + c.g] + qsum(tpx[r]);
+                    if (TEAM) stg(c.ws, c.pn0 + pidx(r, r), lane, S2);
+                    const double t = (TEAM ? gld_d(c.tpg + BS * r + c.g) : lds_d[c.L.tp4 + BS * r + c.g]) + qsum(tpx[r]);
                     if (c.q == 0) lds_d[c.L.tmp + c.g] = lds_d[c.L.y + BS * jr + c.g] - t;
                     wave_lds_sync();
                     double zz = 0.0;
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) zz = fma(S2[rr], lds_d[c.L.tmp + rowof(rr, c.q)], zz);
                     zz = qsum(zz);
-                    if (c.q == 0) lds_d[c.L.z + BS * jr + c.g] = zz;
-                    if (lane == 0) { sh->logdet += ls; if (bad) sh->fail = 1; }
+                    if (c.q == 0) {
+                        lds_d[c.L.z + BS * jr + c.g] = zz;
+                        if (TEAM) gst_d(c.zg + BS * jr + c.g, zz);
+                    }
+                    if (lane == 0) {
+                        sh->logdet += ls;
+                        if (bad) { sh->fail = 1; if (TEAM) __hip_atomic_store(&c.tc->fail, 1, RLX_AGENT); }
+                    }
                     wave_lds_sync();
 #pragma unroll
                     for (int r2 = r + 1; r2 < PR; ++r2) {
@@ -332,6 +452,7 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
                             Dd[pidx(r, r2)] = U;
                             stg(c.ws, jr * NB + j0 + r2, lane, U);
                             stl(c.L.Pn + pidx(r, r2) * BLK, lane, U);
+                            if (TEAM) stg(c.ws, c.pn0 + pidx(r, r2), lane, U);
 #pragma unroll
                             for (int rr = 0; rr < 4; ++rr) tpx[r2] = fma(U[rr], lds_d[c.L.z + BS * jr + rowof(rr, c.q)], tpx[r2]);
                         }
@@ -350,13 +471,27 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
                 }
             }
         }
-        __syncthreads();
+        team_barrier<TEAM>(c);
+        if (TEAM) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tB += t1 - t0; t0 = t1; }
+        if (TEAM) {
+            // the owner's results of (B) for the other members: the panel's factors and U blocks into LDS, its rows of z, and
+            // whether a pivot failed
+            if (c.member != 0) {
+                for (int bb = w; bb < 10; bb += NW) stl(c.L.Pn + bb * BLK, lane, ldg(c.ws, c.pn0 + bb, lane));
+                for (int idx = c.tid; idx < nr * BS; idx += NT) lds_d[c.L.z + BS * j0 + idx] = gld_d(c.zg + BS * j0 + idx);
+                if (c.tid == 0) sh->fail = __hip_atomic_load(&c.tc->fail, RLX_AGENT);
+            }
+            __syncthreads();
+        }
         if (sh->fail) break;
         // ---- (C) columns right of the panel, PCW per wave and step: 4 x PCW accumulators, operands of step k+1 in flight.
         // The factor of an N = 2000 tile lives in HBM / Infinity Cache and this loop runs at what the fabric delivers (5.7 TB/s
         // measured with 4 x 2 accumulators = 0.75 block loads per product); 4 x 3 needs 7 loads per 12 products.
-        constexpr int PCW = 3;
-        for (int i0 = j0 + nr + PCW * w; i0 < NB; i0 += PCW * NW) {
+        // A team deals single columns (4 x 1 accumulators): its time per panel is the k-loop of ONE item (v_mfma_f64_16x16x4
+        // takes 64 cycles: a 4 x 3 item runs 1.3 us per step however many workgroups there are), so more, thinner items
+        // are what more workgroups can use.
+        constexpr int PCW = TEAM ? 1 : 3;
+        for (int i0 = j0 + nr + PCW * c.vw; i0 < NB; i0 += PCW * c.nwt) {
             int ib[PCW];
 #pragma unroll
             for (int cc = 0; cc < PCW; ++cc) ib[cc] = (i0 + cc < NB) ? i0 + cc : -1;
@@ -428,7 +563,14 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
                 }
             }
         }
-        __syncthreads();
+        team_barrier<TEAM>(c);
+        if (TEAM) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tC += t1 - t0; t0 = t1; }
+    }
+    if (TEAM && c.tid == 0 && c.member == 0) {       // developer: 100 MHz ticks of the owner's thread 0 per part (GPSAT_DEBUG_TEAM_STATS)
+        __hip_atomic_fetch_add(&c.tc->pad1[0], (int)tW, RLX_AGENT);
+        __hip_atomic_fetch_add(&c.tc->pad1[1], (int)tA, RLX_AGENT);
+        __hip_atomic_fetch_add(&c.tc->pad1[2], (int)tB, RLX_AGENT);
+        __hip_atomic_fetch_add(&c.tc->pad1[3], (int)tC, RLX_AGENT);
     }
     __syncthreads();
 }
@@ -436,15 +578,19 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
 // ---- phase 2: M = L^-1 (lower slots), alpha = M^T z, by panels of PR block rows (same blocking as phase_potrf:
 // a wave owns pairs of block columns, 4 x 2 accumulators, every streamed block is loaded once per 4 products):
 //   M_ij = -L_i^-1 sum_{k=j}^{i-1} U_ki^T M_kj   (M_jj = L_j^-1 already in the diagonal slot)
-template <int D, int KN>
+// Team: alpha lives in the owner's workspace (one writer per column and panel; panels separated by team barriers, so every
+// column's sum keeps the order it has in one workgroup) and comes into every member's LDS at the end.
+template <int D, int KN, bool TEAM>
 __device__ __forceinline__ void phase_trtri(Ctx<D, KN>& c) {
-    const int NB = c.NB, lane = c.lane, w = c.w;
+    const int NB = c.NB, lane = c.lane;
     for (int idx = c.tid; idx < c.Npad; idx += NT) lds_d[c.L.alpha + idx] = 0.0;
-    __syncthreads();
+    if (TEAM && c.member == 0)
+        for (int idx = c.tid; idx < c.Npad; idx += NT) gst_d(c.ag + idx, 0.0);
+    team_barrier<TEAM>(c);
     for (int i0 = 0; i0 < NB; i0 += PR) {
         const int nr = min(PR, NB - i0);
         // (1) column pairs left of the panel
-        for (int p = w; 2 * p < i0; p += NW) {
+        for (int p = c.vw; 2 * p < i0; p += c.nwt) {
             const int jc0 = 2 * p, jc1 = jc0 + 1;
             f64x4 acc[PR][2];
 #pragma unroll
@@ -502,12 +648,18 @@ __device__ __forceinline__ void phase_trtri(Ctx<D, KN>& c) {
             }
             ap0 = qsum(ap0); ap1 = qsum(ap1);
             if (c.q == 0) {                              // a column pair always belongs to the same wave: no race
-                lds_d[c.L.alpha + BS * jc0 + c.g] += ap0;
-                lds_d[c.L.alpha + BS * jc1 + c.g] += ap1;
+                if (TEAM) {
+                    gdouble *a0 = c.ag + BS * jc0 + c.g, *a1 = c.ag + BS * jc1 + c.g;
+                    gst_d(a0, gld_d(a0) + ap0);
+                    gst_d(a1, gld_d(a1) + ap1);
+                } else {
+                    lds_d[c.L.alpha + BS * jc0 + c.g] += ap0;
+                    lds_d[c.L.alpha + BS * jc1 + c.g] += ap1;
+                }
             }
         }
         // (2) the triangle inside the panel (one wave, the next in the round-robin of (1))
-        if (w == ((i0 >> 1) & (NW - 1))) {
+        if (c.vw == ((i0 >> 1) % c.nwt)) {
             for (int j = i0; j < i0 + nr; ++j) {
                 const f64x4 Mjj = ldg(c.ws, j * NB + j, lane);
                 double ap = 0.0;
@@ -525,13 +677,23 @@ __device__ __forceinline__ void phase_trtri(Ctx<D, KN>& c) {
                     mma_blk(Mij, Lop, acc);
                     Mij = -Mij;
                     stg(c.ws, i * NB + j, lane, Mij);
+                    // this wave reads the block back a few instructions later (k = i of the next row): a write-through store
+                    // still on its way is not ordered before a load of the same bytes
+                    if (TEAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) ap = fma(Mij[rr], lds_d[c.L.z + BS * i + rowof(rr, c.q)], ap);
                 }
                 const double a = qsum(ap);
-                if (c.q == 0) lds_d[c.L.alpha + BS * j + c.g] += a;
+                if (c.q == 0) {
+                    if (TEAM) { gdouble* aj = c.ag + BS * j + c.g; gst_d(aj, gld_d(aj) + a); }
+                    else lds_d[c.L.alpha + BS * j + c.g] += a;
+                }
             }
         }
+        team_barrier<TEAM>(c);
+    }
+    if (TEAM) {
+        for (int idx = c.tid; idx < c.Npad; idx += NT) lds_d[c.L.alpha + idx] = gld_d(c.ag + idx);
         __syncthreads();
     }
 }
@@ -539,19 +701,19 @@ __device__ __forceinline__ void phase_trtri(Ctx<D, KN>& c) {
 // ---- phase 3: K^-1 blocks (K^-1)_ab = sum_{c>=a} M_ca^T M_cb, a >= b, contracted with dK/dtheta: 4 block rows a x
 // 2 block columns b per wave and step (the same 4 x 2 blocking; operands that would fall above the diagonal are the
 // zero block)
-template <int D, int KN>
+// Every item (4 block rows x 2 block columns) leaves its D + 2 partial sums PER LANE in the workspace (gpart, aliasing the
+// prediction scratch, idle during an evaluation); they are added in a fixed order by the owner -- the gradient does not
+// depend on how the items were dealt over waves and workgroups.
+template <int D, int KN, bool TEAM>
 __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
     Shared* sh = reinterpret_cast<Shared*>(lds_d);
     const int NB = c.NB, lane = c.lane;
-    double accl[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) accl[d] = 0.0;
-    double accsf = 0.0, accsn = 0.0;
+    double* gpart = reinterpret_cast<double*>(reinterpret_cast<char*>(c.ws) + c.gp0);
     int item = 0;
     for (int a0 = 0; a0 < NB; a0 += PR) {
         const int na = min(PR, NB - a0);
         for (int b0 = 0; b0 < a0 + na; b0 += 2, ++item) {
-            if ((item & (NW - 1)) != c.w) continue;
+            if ((item % c.nwt) != c.vw) continue;
             const bool hb1 = b0 + 1 < NB;
             f64x4 acc[PR][2];
 #pragma unroll
@@ -581,6 +743,10 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
                     for (int r = 0; r < PR; ++r) { mma_blk(acc[r][0], A[r], B0); mma_blk(acc[r][1], A[r], B1); }
                 }
             }
+            double accl[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) accl[d] = 0.0;
+            double accsf = 0.0, accsn = 0.0;
 #pragma unroll
             for (int r = 0; r < PR; ++r) {
 #pragma unroll
@@ -590,13 +756,33 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
                         contract<D, KN>(c, acc[r][n], a, b, (a == b) ? 1.0 : 2.0, accl, accsf, accsn);
                 }
             }
+            double* gp = gpart + (size_t)item * (D + 2) * 64 + lane;
+            if (TEAM) {
+                gdouble* gg = (gdouble*)gp;
+#pragma unroll
+                for (int d = 0; d < D; ++d) gst_d(gg + d * 64, accl[d]);
+                gst_d(gg + D * 64, accsf);
+                gst_d(gg + (D + 1) * 64, accsn);
+            } else {
+#pragma unroll
+                for (int d = 0; d < D; ++d) gp[d * 64] = accl[d];
+                gp[D * 64] = accsf;
+                gp[(D + 1) * 64] = accsn;
+            }
         }
     }
+    const int nitems = item;
+    team_barrier<TEAM>(c);
+    if (c.member != 0) return;
+    // fixed-order sum: wave w adds the items w, w + NW, ... per lane, then across lanes, then across waves
     double v[D + 2];
 #pragma unroll
-    for (int d = 0; d < D; ++d) v[d] = accl[d];
-    v[D] = accsf;
-    v[D + 1] = accsn;
+    for (int i = 0; i < D + 2; ++i) v[i] = 0.0;
+    for (int it = c.w; it < nitems; it += NW) {
+        const double* gp = gpart + (size_t)it * (D + 2) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < D + 2; ++i) v[i] += TEAM ? gld_d((const gdouble*)(gp + i * 64)) : gp[i * 64];
+    }
 #pragma unroll
     for (int i = 0; i < D + 2; ++i) {
 #pragma unroll
@@ -618,7 +804,7 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
     __syncthreads();
 }
 
-template <int D, int KN>
+template <int D, int KN, bool TEAM>
 __device__ __forceinline__ void evaluate(Ctx<D, KN>& c, bool want_grad, const double* __restrict__ Xg) {
     Shared* sh = reinterpret_cast<Shared*>(lds_d);
     __syncthreads();
@@ -629,7 +815,7 @@ __device__ __forceinline__ void evaluate(Ctx<D, KN>& c, bool want_grad, const do
         for (int d = 0; d < D; ++d) lds_d[c.L.xsc + d * c.Npad + idx] = (idx < c.N) ? Xg[(size_t)idx * D + d] / sh->theta[d] : 0.0;
     }
     __syncthreads();
-    phase_potrf<D, KN>(c);
+    phase_potrf<D, KN, TEAM>(c);
     if (sh->fail) {
         if (c.tid == 0) { sh->nll = __builtin_inf(); for (int i = 0; i < D + 2; ++i) sh->gth[i] = 0.0; }
         __syncthreads();
@@ -648,8 +834,8 @@ __device__ __forceinline__ void evaluate(Ctx<D, KN>& c, bool want_grad, const do
     }
     __syncthreads();
     if (want_grad) {
-        phase_trtri<D, KN>(c);
-        phase_grad<D, KN>(c);
+        phase_trtri<D, KN, TEAM>(c);
+        phase_grad<D, KN, TEAM>(c);
     }
     if (c.tid == 0) {
         sh->n_eval += 1;
@@ -658,7 +844,7 @@ __device__ __forceinline__ void evaluate(Ctx<D, KN>& c, bool want_grad, const do
     __syncthreads();
 }
 
-template <int D, int KN>
+template <int D, int KN, bool TEAM>
 __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const double* __restrict__ Xs, double* __restrict__ fm,
                                              double* __restrict__ fv, double* __restrict__ yv, const double* theta,
                                              double* __restrict__ fcov) {
@@ -735,6 +921,7 @@ __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const double* __rest
                     }
                 }
             }
+            if (TEAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the V blocks stored above are this wave's next operands
         }
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
@@ -748,6 +935,7 @@ __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const double* __rest
     }
     if (fcov) {
         // f*_cov = K_** - V^T V by 16 x 16 blocks (p <= q, mirrored), gpflow_models.py:245-263 (predict_f full_cov)
+        if (TEAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // write-through V blocks of the other waves
         __syncthreads();
         int idx = 0;
         for (int p = 0; p < PC; ++p) {
@@ -817,6 +1005,7 @@ __global__ void __launch_bounds__(NT, F64_MIN_WG) gp_tile_kernel_f64(const Kerne
     c.ws = wsall + (size_t)blockIdx.x * stride;
     c.zb = (int)(stride / BLK) - 1;
     for (int i = c.tid; i < BLK; i += NT) c.ws[(size_t)c.zb * BLK + i] = 0.0;
+    c.vw = c.w; c.nwt = NW; c.member = 0; c.G = 1; c.tc = nullptr; c.pn0 = 0; c.tpg = nullptr; c.zg = nullptr; c.ag = nullptr;
     const double* X = reinterpret_cast<const double*>(A.X);
     const double* y = reinterpret_cast<const double*>(A.y);
     const double* Xs = reinterpret_cast<const double*>(A.Xs);
@@ -854,6 +1043,7 @@ __global__ void __launch_bounds__(NT, F64_MIN_WG) gp_tile_kernel_f64(const Kerne
         c.dT0 = NB * NB;
         c.vs0 = c.dT0 + NB;
         c.cv0 = c.vs0 + NW * 4 * NB;
+        c.gp0 = c.vs0 * (BLK * 8);
         if (c.N == 0) {
             if (c.tid == 0) {
                 A.status[t] = 4; A.n_eval[t] = 0; A.nll[t] = 0.0;
@@ -920,7 +1110,7 @@ __global__ void __launch_bounds__(NT, F64_MIN_WG) gp_tile_kernel_f64(const Kerne
         const int seg_evals = sliced ? max(1, A.seg_cost / (NB * NB * NB)) : 0x7fffffff;
         bool suspended = false;
         for (int nseg = 1;; ++nseg) {
-            evaluate<D, KN>(c, sh->want_grad != 0, X + (size_t)o0 * D);
+            evaluate<D, KN, false>(c, sh->want_grad != 0, X + (size_t)o0 * D);
             if (c.tid == 0) opt_advance(sh, H, o);
             __syncthreads();
             if (sh->phase == PH_EXIT) break;
@@ -951,7 +1141,7 @@ __global__ void __launch_bounds__(NT, F64_MIN_WG) gp_tile_kernel_f64(const Kerne
         }
         if (c.P > 0) {
             if (!sh->fail) {
-                predict_tile<D, KN>(c, Xs + (size_t)p0 * D, f_mean + p0, f_var + p0, y_var + p0, sh->theta,
+                predict_tile<D, KN, false>(c, Xs + (size_t)p0 * D, f_mean + p0, f_var + p0, y_var + p0, sh->theta,
                                     f_cov ? f_cov + A.cov_off[t] : nullptr);
             } else {
                 for (long long qq = p0 + c.tid; qq < p1; qq += NT) {
@@ -965,8 +1155,212 @@ __global__ void __launch_bounds__(NT, F64_MIN_WG) gp_tile_kernel_f64(const Kerne
     }
 }
 
+#ifndef GPSAT_F64_W4
+// ---------------------------------------------------------------------------------------------
+// the team kernel: KernelArgs::team_size workgroups per tile (see "Teams" above).  Workgroup b is member b % G of team
+// b / G; the team's workspace is the slab of its member 0.  The owner pops tiles, runs the optimiser and, before every
+// evaluation, publishes parameters and a command in the team's control block; everybody meets at the command barrier.
+// ---------------------------------------------------------------------------------------------
+template <int D, int KN>
+__global__ void __launch_bounds__(NT, 1) gp_team_kernel_f64(const KernelArgs A) {
+    constexpr int H = D + 2;
+    constexpr bool TEAM = true;
+    Ctx<D, KN> c;
+    c.tid = threadIdx.x;
+    c.lane = c.tid & 63;
+    c.w = c.tid >> 6;
+    c.q = c.lane >> 4;
+    c.g = c.lane & 15;
+    const int NPmax = A.NBmax * BS;
+    Shared* sh = reinterpret_cast<Shared*>(lds_d);
+    int off = (int)((sizeof(Shared) + 15) / 16) * 2;
+    c.L.xsc = off; off += D * NPmax;
+    c.L.y = off; off += NPmax;
+    c.L.z = off; off += NPmax;
+    c.L.alpha = off; off += NPmax;
+    c.L.LT = off; off += BLK;
+    c.L.Ad = off; off += 16 * 17;
+    c.L.tmp = off; off += 16;
+    c.L.Pn = off; off += 10 * BLK;
+    c.L.tp4 = off; off += 4 * BS;
+    const int G = A.team_size;
+    c.G = G;
+    c.member = (int)blockIdx.x % G;
+    const int team = (int)blockIdx.x / G;
+    c.vw = c.member * NW + c.w;
+    c.nwt = NW * G;
+    c.tc = (gTeamCtl*)A.team_ctl + team;
+    const size_t stride = A.ws_stride;
+    c.ws = reinterpret_cast<double*>(A.ws) + (size_t)team * stride;               // one slab per team
+    c.zb = (int)(stride / BLK) - 1;
+    c.pn0 = c.zb - 40;
+    c.tpg = (gdouble*)(c.ws + (size_t)(c.zb - 29) * BLK);
+    c.zg = (gdouble*)(c.ws + (size_t)(c.zb - 28) * BLK);
+    c.ag = (gdouble*)(c.ws + (size_t)(c.zb - 14) * BLK);
+    if (c.member == 0 && c.w == 0) { const f64x4 z0 = zero4(); stg(c.ws, c.zb, c.lane, z0); }
+    if (c.tid == 0) sh->hp[0] = 0;                      // team barriers passed
+    const double* X = reinterpret_cast<const double*>(A.X);
+    const double* y = reinterpret_cast<const double*>(A.y);
+    const double* Xs = reinterpret_cast<const double*>(A.Xs);
+    double* f_mean = reinterpret_cast<double*>(A.f_mean);
+    double* f_var = reinterpret_cast<double*>(A.f_var);
+    double* f_cov = reinterpret_cast<double*>(A.f_cov);
+    double* y_var = reinterpret_cast<double*>(A.y_var);
+    OptCfg o;
+    o.optimiser = A.optimiser; o.max_iter = A.max_iter; o.max_ls = A.max_ls; o.want_grad_out = A.grad != nullptr;
+    o.ftol = A.ftol; o.gtol = A.gtol; o.adam_lr = A.adam_lr; o.noise_rel = A.noise_rel;
+    __syncthreads();
+
+    auto set_tile = [&](int t) {
+        const long long o0 = A.obs_off[t], o1 = A.obs_off[t + 1];
+        c.N = (int)(o1 - o0);
+        c.P = (int)(A.pred_off[t + 1] - A.pred_off[t]);
+        c.NB = (c.N + BS - 1) / BS;
+        c.Npad = c.NB * BS;
+        c.dT0 = c.NB * c.NB;
+        c.vs0 = c.dT0 + c.NB;
+        c.cv0 = c.vs0 + NW * 4 * c.NB;
+        c.gp0 = c.vs0 * (BLK * 8);
+    };
+
+    if (c.member != 0) {
+        // ---- a member: follow the owner's commands
+        int t = -1;
+        for (;;) {
+            team_barrier<TEAM>(c);                                         // the command barrier
+            if (c.tid == 0) {
+                sh->hp[1] = __hip_atomic_load(&c.tc->cmd, RLX_AGENT);
+                sh->hp[2] = __hip_atomic_load(&c.tc->tile, RLX_AGENT);
+                sh->hp[3] = __hip_atomic_load(&c.tc->want_grad, RLX_AGENT);
+                if (__hip_atomic_load(&c.tc->timeout, RLX_AGENT)) sh->hp[1] = TEAM_EXIT;
+                for (int i = 0; i < H; ++i) sh->theta[i] = gld_d(&c.tc->theta[i]);
+            }
+            __syncthreads();
+            const int cmd = sh->hp[1];
+            if (cmd == TEAM_EXIT) break;
+            if (cmd == TEAM_TILE) { t = sh->hp[2]; set_tile(t); continue; }
+            evaluate<D, KN, TEAM>(c, sh->hp[3] != 0, X + (size_t)A.obs_off[t] * D);
+        }
+        return;
+    }
+
+    // ---- the owner
+    auto command = [&](int cmd, int t, int want_grad) {
+        if (c.tid == 0) {
+            __hip_atomic_store(&c.tc->tile, t, RLX_AGENT);
+            __hip_atomic_store(&c.tc->want_grad, want_grad, RLX_AGENT);
+            for (int i = 0; i < H; ++i) gst_d(&c.tc->theta[i], sh->theta[i]);
+            __hip_atomic_store(&c.tc->fail, 0, RLX_AGENT);
+            __hip_atomic_store(&c.tc->cmd, cmd, RLX_AGENT);
+        }
+        team_barrier<TEAM>(c);
+    };
+    for (;;) {
+        __syncthreads();
+        if (c.tid == 0) {
+            const int slot = atomicAdd(A.queue, 1);
+            sh->tile = slot < A.T ? A.order[slot] : -1;
+            if (__hip_atomic_load(&c.tc->timeout, RLX_AGENT)) sh->tile = -1;
+        }
+        __syncthreads();
+        const int t = sh->tile;
+        if (t == -1) { command(TEAM_EXIT, 0, 0); break; }
+        const long long o0 = A.obs_off[t];
+        const long long p0 = A.pred_off[t], p1 = A.pred_off[t + 1];
+        set_tile(t);
+        if (c.N == 0) {
+            if (c.tid == 0) {
+                A.status[t] = 4; A.n_eval[t] = 0; A.nll[t] = 0.0;
+                if (A.n_iter) A.n_iter[t] = 0;
+                for (int i = 0; i < H; ++i) {
+                    A.theta[(size_t)t * H + i] = A.theta0[(size_t)t * H + i];
+                    if (A.grad) A.grad[(size_t)t * H + i] = 0.0;
+                }
+            }
+            for (long long qq = p0 + c.tid; qq < p1; qq += NT) {
+                const double sf2 = A.theta0[(size_t)t * H + D], sn2 = A.theta0[(size_t)t * H + D + 1];
+                f_mean[qq] = 0.0; f_var[qq] = sf2; y_var[qq] = sf2 + sn2;
+            }
+            if (f_cov)
+                for (long long qq = A.cov_off[t] + c.tid; qq < A.cov_off[t + 1]; qq += NT) f_cov[qq] = __builtin_nan("");
+            continue;
+        }
+        for (int idx = c.tid; idx < c.Npad; idx += NT) {
+            lds_d[c.L.y + idx] = (idx < c.N) ? y[o0 + idx] : 0.0;
+            lds_d[c.L.z + idx] = 0.0;
+            lds_d[c.L.alpha + idx] = 0.0;
+        }
+        if (c.tid == 0) {
+            sh->n_eval = 0; sh->n_eval_opt = 0; sh->status = 5; sh->iter = 0; sh->hist_n = 0; sh->hist_pos = 0;
+            sh->last_dec = 1e300;
+            sh->fail = 0;
+            for (int i = 0; i < H; ++i) {
+                const double lo = A.lo[(size_t)t * H + i], hi = A.hi[(size_t)t * H + i];
+                const bool box = (lo == lo) && (hi == hi) && (fabs(lo) < 1e300) && (fabs(hi) < 1e300);
+                sh->box[i] = box ? 1 : 0;
+                sh->lo[i] = lo; sh->hi[i] = hi;
+                sh->shift[i] = (!box && i == D + 1) ? 1e-6 : 0.0;
+                sh->trainable[i] = A.trainable[i] ? 1 : 0;
+                sh->theta[i] = A.theta0[(size_t)t * H + i];
+                sh->u[i] = u_of_theta(sh, i, sh->theta[i]);
+                sh->m1[i] = 0.0; sh->m2[i] = 0.0;
+            }
+            const bool optim = (o.optimiser != 0 && o.max_iter > 0);
+            sh->phase = optim ? PH_INIT : PH_FINAL;
+            sh->want_grad = optim ? 1 : o.want_grad_out;
+        }
+        __syncthreads();
+        command(TEAM_TILE, t, 0);
+        for (;;) {
+            command(TEAM_EVAL, t, sh->want_grad);
+            evaluate<D, KN, TEAM>(c, sh->want_grad != 0, X + (size_t)o0 * D);
+            if (c.tid == 0) {
+                if (__hip_atomic_load(&c.tc->timeout, RLX_AGENT)) sh->fail = 1;       // a barrier gave up: nothing of this is valid
+                opt_advance(sh, H, o);
+                if (__hip_atomic_load(&c.tc->timeout, RLX_AGENT)) sh->phase = PH_EXIT;
+            }
+            __syncthreads();
+            if (sh->phase == PH_EXIT) break;
+        }
+        if (c.tid == 0) {
+            int st = sh->status;
+            if (sh->fail) st = (sh->nll == sh->nll) ? 2 : 3;
+            A.status[t] = st;
+            A.n_eval[t] = sh->n_eval_opt;
+            if (A.n_iter) A.n_iter[t] = sh->iter;
+            A.nll[t] = sh->fail ? __builtin_nan("") : sh->nll;
+            for (int i = 0; i < H; ++i) {
+                A.theta[(size_t)t * H + i] = sh->theta[i];
+                if (A.grad) A.grad[(size_t)t * H + i] = sh->fail ? __builtin_nan("") : sh->gth[i];
+            }
+        }
+        if (c.P > 0) {
+            if (!sh->fail) {
+                predict_tile<D, KN, TEAM>(c, Xs + (size_t)p0 * D, f_mean + p0, f_var + p0, y_var + p0, sh->theta,
+                                          f_cov ? f_cov + A.cov_off[t] : nullptr);
+            } else {
+                for (long long qq = p0 + c.tid; qq < p1; qq += NT) {
+                    f_mean[qq] = __builtin_nan(""); f_var[qq] = __builtin_nan(""); y_var[qq] = __builtin_nan("");
+                }
+                if (f_cov)
+                    for (long long qq = A.cov_off[t] + c.tid; qq < A.cov_off[t + 1]; qq += NT) f_cov[qq] = __builtin_nan("");
+            }
+        }
+    }
+}
+#endif
+
 template <int D, int KN>
 static hipError_t launch_one(const KernelArgs& a, int grid, size_t smem, hipStream_t stream) {
+#ifndef GPSAT_F64_W4
+    if (a.team_size > 1) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gp_team_kernel_f64<D, KN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((gp_team_kernel_f64<D, KN>), dim3(grid), dim3(NT), smem, stream, a);
+        return hipGetLastError();
+    }
+#endif
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gp_tile_kernel_f64<D, KN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
@@ -998,7 +1392,8 @@ int F64FN(state_words_f64)() { return (int)((sizeof(F64NS::Shared) + 15) / 16) *
 size_t F64FN(workspace_doubles_per_wg_f64)(int NBmax, int PCcov) {
     // + V of all prediction chunks when the full covariance is wanted (spare chunks: a wave always solves 2 at a time)
     const size_t cov = PCcov > 0 ? (size_t)(PCcov + 3) * NBmax : 0;
-    return (size_t)F64NS::BLK * ((size_t)NBmax * NBmax + (size_t)NBmax + (size_t)F64NS::NW * 4 * NBmax + cov + 1);
+    // ... 40 blocks of exchange areas for teams (diagonal region of a panel, z, alpha), and the zero block
+    return (size_t)F64NS::BLK * ((size_t)NBmax * NBmax + (size_t)NBmax + (size_t)F64NS::NW * 4 * NBmax + cov + 40 + 1);
 }
 
 hipError_t F64FN(launch_tiles_f64)(int D, const KernelArgs& a, int grid, size_t smem, hipStream_t stream) {
