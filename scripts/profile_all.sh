@@ -2,7 +2,7 @@
 # Profile every shape / kernel of the path on the GPU box.  For each workload: one `rocprofv3 --kernel-trace --stats` run
 # and SEPARATE `--pmc` passes (never combined with other trace domains); raw traces are summarised by
 # scripts/collect_profile.py into gpurun_out/<TAG>/<workload>/ and deleted.  Copy what is to be judged into profiles/.
-#   scripts/profile_all.sh TAG [workload ...]      workloads: configs1 configs2 configs4 f64fit select post
+#   scripts/profile_all.sh TAG [workload ...]      workloads: configs1 configs2 configs2_1024 configs4 f64fit select post
 set -e
 TAG=${1:-prof}; shift || true
 WLS=${@:-configs1 configs2 configs4 f64fit select post}
@@ -12,10 +12,11 @@ for WL in $WLS; do
   OUT=$ROOT/gpurun_out/$TAG/$WL; mkdir -p $OUT
   MFMA=SQ_INSTS_VALU_MFMA_F32; PAT=gp_tile_kernel; ST="--steps 3 --warmup 1"; ONE="--steps 1 --warmup 0"
   case $WL in
-    configs1) CMD="$ROOT/bench.py --cpu-tiles 0 --workers 1 --no-host-leg";;
-    configs2) CMD="$ROOT/bench.py --cpu-tiles 0 --workers 1 --no-host-leg --workload configs2";;
-    configs4) CMD="$ROOT/bench.py --cpu-tiles 0 --workers 1 --no-host-leg --workload configs4"; MFMA=SQ_INSTS_VALU_MFMA_F64;;
-    f64fit)   CMD="$ROOT/scripts/f64_fit.py"; MFMA=SQ_INSTS_VALU_MFMA_F64; ST=""; ONE="";;
+    configs1) CMD="$ROOT/bench.py --cpu-tiles 0 --workers 1 --no-host-leg --no-quality";;
+    configs2) CMD="$ROOT/bench.py --cpu-tiles 0 --workers 1 --no-host-leg --no-quality --workload configs2";;
+    configs2_1024) CMD="$ROOT/bench.py --cpu-tiles 0 --workers 1 --no-host-leg --no-quality --workload configs2 --tiles 1024";;
+    configs4) CMD="$ROOT/bench.py --cpu-tiles 0 --workers 1 --no-host-leg --no-quality --workload configs4"; MFMA=SQ_INSTS_VALU_MFMA_F64;;
+    f64fit)   CMD="$ROOT/bench.py --cpu-tiles 0 --workers 1 --no-host-leg --no-quality --workload f64fit"; MFMA=SQ_INSTS_VALU_MFMA_F64;;
     select)   CMD="$ROOT/scripts/select_bench.py"; PAT=select; ST=""; ONE="";;
     post)     CMD="$ROOT/scripts/post_bench.py"; PAT="smooth|glue"; ST=""; ONE="";;
   esac
