@@ -490,7 +490,9 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
         // A team deals single columns (4 x 1 accumulators): its time per panel is the k-loop of ONE item (v_mfma_f64_16x16x4
         // takes 64 cycles: a 4 x 3 item runs 1.3 us per step however many workgroups there are), so more, thinner items
         // are what more workgroups can use.
-        constexpr int PCW = TEAM ? 1 : 3;
+        // The 4-wave build (small tiles, at most ~9 column triples per panel for 4 waves) deals pairs: the finer items
+        // balance better (fp64 fit of N = 500 tiles +3.4 %; single columns: the same).
+        constexpr int PCW = TEAM ? 1 : (NW == 4 ? 2 : 3);
         for (int i0 = j0 + nr + PCW * c.vw; i0 < NB; i0 += PCW * c.nwt) {
             int ib[PCW];
 #pragma unroll
