@@ -63,9 +63,19 @@ struct gpsat_handle {
     double last_kernel_ms = 0.0, last_total_ms = 0.0;
     bool force_unsliced = false;       // retry of a batch whose time-sliced queue ended with unfinished tiles
     bool force_solo = false;           // retry of a batch in which a team barrier gave up
+    // gpsat_select_batch is called twice per selection (sizes, then indices): the first call already leaves the indices on
+    // the device; the second, when it repeats the first call's arguments, only copies them out
+    struct {
+        const void *pts = nullptr, *refs = nullptr;
+        int64_t M = 0, total = -1;
+        int C = 0, T = 0;
+        gpsat_select_spec sp;
+        const int* d_result = nullptr;
+        std::vector<int64_t> off;
+    } selc;
     // device buffers (grown lazily, owned by the handle)
     DevBuf meta_i64, meta_f64, meta_misc, out_f64, out_i32, bulk_in, bulk_out, ws, prof, ring, state, coop;
-    DevBuf sel_pts, sel_refs, sel_cnt, sel_idx, sel_box;
+    DevBuf sel_pts, sel_refs, sel_cnt, sel_idx, sel_box, sel_perm, sel_keys, sel_tmp, sel_ord;
     unsigned long long prof_host[64 + 8 * 1024 + 2048] = {0};     // counters + event trace + per-workgroup start / end (diagnostic build)
 };
 
@@ -132,6 +142,7 @@ int gpsat_destroy(gpsat_handle* h) {
     h->meta_i64.release(); h->meta_f64.release(); h->meta_misc.release(); h->out_f64.release();
     h->out_i32.release(); h->bulk_in.release(); h->bulk_out.release(); h->ws.release(); h->prof.release(); h->ring.release(); h->state.release(); h->coop.release();
     h->sel_pts.release(); h->sel_refs.release(); h->sel_cnt.release(); h->sel_idx.release(); h->sel_box.release();
+    h->sel_perm.release(); h->sel_keys.release(); h->sel_tmp.release(); h->sel_ord.release();
     for (int i = 0; i < 4; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -485,6 +496,17 @@ int gpsat_select_batch(gpsat_handle* h, const gpsat_select_spec* sp, int64_t M, 
     off[0] = 0;
     if (T == 0) return GPSAT_OK;
     if ((M > 0 && !points) || !refs) return fail(GPSAT_EINVAL, "gpsat_select_batch: NULL table");
+    if (idx && h->selc.total >= 0 && h->selc.pts == points && h->selc.refs == refs && h->selc.M == M && h->selc.C == C &&
+        h->selc.T == T && std::memcmp(&h->selc.sp, sp, sizeof(*sp)) == 0) {
+        const int64_t total = h->selc.total;
+        h->selc.total = -1;
+        std::memcpy(off, h->selc.off.data(), (size_t)(T + 1) * sizeof(int64_t));
+        if (capacity < total) return fail(GPSAT_EINVAL, "gpsat_select_batch: idx capacity too small (see off[T])");
+        HIP_TRY(hipSetDevice(h->device));
+        if (total > 0) HIP_TRY(hipMemcpy(idx, h->selc.d_result, (size_t)total * sizeof(int), hipMemcpyDeviceToHost));
+        return GPSAT_OK;
+    }
+    h->selc.total = -1;
     HIP_TRY(hipSetDevice(h->device));
     int rc;
     if ((rc = h->sel_pts.reserve(std::max<size_t>((size_t)M * C, 1) * sizeof(double)))) return rc;
@@ -502,11 +524,73 @@ int gpsat_select_batch(gpsat_handle* h, const gpsat_select_spec* sp, int64_t M, 
     HIP_TRY(hipMemcpyAsync(h->sel_refs.p, refs, (size_t)T * C * sizeof(double), hipMemcpyHostToDevice, h->stream));
     a.M = M; a.C = C; a.T = T;
     a.n_chunks = n_chunks; a.chunk_rows = chunk_rows;
+    a.eorder = nullptr;
     a.pts = static_cast<const double*>(h->sel_pts.p);
-    a.refs = static_cast<const double*>(h->sel_refs.p);
-    a.counts = static_cast<long long*>(h->sel_cnt.p);
+    // ---- spatial binning (gpsat_select.hip): large tables are sorted on the device by the grid cell of the criteria's
+    // columns -- a ball criterion's columns with cells of its radius, a two-sided 1-D window's column with cells of half its
+    // width, at most three columns -- and the experts are dealt to the waves in the order of their own cells
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+    gpsat::BinSpec bin;
+    bin.ndim = 0;
+    const int* d_perm = nullptr;
+    if (M >= 65536 && !std::getenv("GPSAT_DEBUG_NO_BINNING")) {
+        auto add_dim = [&](int col, double cell) {
+            if (bin.ndim >= 3 || !(cell > 0.0) || !std::isfinite(cell)) return;
+            for (int d = 0; d < bin.ndim; ++d) if (bin.col[d] == col) return;
+            double mn = INFINITY, mx = -INFINITY;
+            const double* x = points + (size_t)col * M;
+            for (int64_t i = 0; i < M; ++i) { const double v = x[i]; if (v < mn) mn = v; if (v > mx) mx = v; }
+            if (!(mn <= mx) || !std::isfinite(mn) || !std::isfinite(mx)) return;
+            const double nc = std::min(1024.0, std::max(1.0, std::ceil((mx - mn) / cell)));
+            bin.col[bin.ndim] = col; bin.origin[bin.ndim] = mn; bin.ncell[bin.ndim] = (int)nc;
+            bin.inv_cell[bin.ndim] = (mx > mn) ? nc / (mx - mn) : 0.0;
+            ++bin.ndim;
+        };
+        for (int k = 0; k < a.n_crit; ++k) {              // two-sided windows first (GPSat: the time column)
+            if (a.kind[k] != 0 || !(a.comp[k] == 3 || a.comp[k] == 4)) continue;
+            for (int k2 = 0; k2 < a.n_crit; ++k2)
+                if (a.kind[k2] == 0 && (a.comp[k2] == 0 || a.comp[k2] == 1) && a.cols[k2][0] == a.cols[k][0] && a.val[k] > a.val[k2])
+                    add_dim(a.cols[k][0], 0.5 * (a.val[k] - a.val[k2]));
+        }
+        for (int k = 0; k < a.n_crit; ++k)
+            if (a.kind[k] == 1) for (int m = 0; m < a.ncols[k]; ++m) add_dim(a.cols[k][m], a.val[k]);
+    }
+    if (bin.ndim > 0) {
+        const size_t perm_bytes = ((size_t)M * 2 * sizeof(int) + 255) & ~size_t(255);
+        if ((rc = h->sel_perm.reserve(perm_bytes + (size_t)M * C * sizeof(double)))) return rc;
+        if ((rc = h->sel_keys.reserve((size_t)M * 2 * sizeof(unsigned)))) return rc;
+        int* d_rows = static_cast<int*>(h->sel_perm.p);
+        int* d_p = d_rows + M;
+        double* d_pp = reinterpret_cast<double*>(static_cast<char*>(h->sel_perm.p) + perm_bytes);
+        unsigned* d_k = static_cast<unsigned*>(h->sel_keys.p);
+        size_t tb = 0;
+        HIP_TRY(gpsat::select_bin_rows(M, C, a.pts, bin, d_k, d_k + M, d_rows, d_p, d_pp, nullptr, tb, h->stream));
+        if ((rc = h->sel_tmp.reserve(std::max<size_t>(tb, 16)))) return rc;
+        HIP_TRY(gpsat::select_bin_rows(M, C, a.pts, bin, d_k, d_k + M, d_rows, d_p, d_pp, h->sel_tmp.p, tb, h->stream));
+        a.pts = d_pp;
+        d_perm = d_p;
+        // experts by their own cell
+        std::vector<unsigned> ekey(T);
+        for (int t = 0; t < T; ++t) {
+            unsigned key = 0;
+            for (int d = 0; d < bin.ndim; ++d) {
+                const double cf = (refs[(size_t)t * C + bin.col[d]] - bin.origin[d]) * bin.inv_cell[d];
+                const int cell = (cf >= 0.0) ? (int)std::min(cf, (double)(bin.ncell[d] - 1)) : 0;
+                key = key * (unsigned)bin.ncell[d] + (unsigned)cell;
+            }
+            ekey[t] = key;
+        }
+        std::vector<int> eord(T);
+        std::iota(eord.begin(), eord.end(), 0);
+        std::stable_sort(eord.begin(), eord.end(), [&](int x, int y) { return ekey[x] < ekey[y]; });
+        if ((rc = h->sel_ord.reserve((size_t)T * sizeof(int) + (size_t)(T + 1) * sizeof(unsigned)))) return rc;
+        HIP_TRY(hipMemcpyAsync(h->sel_ord.p, eord.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));          // `eord` is local host memory
+        a.eorder = static_cast<const int*>(h->sel_ord.p);
+    }
+    a.refs = static_cast<const double*>(h->sel_refs.p);
+    a.counts = static_cast<long long*>(h->sel_cnt.p);
     a.box = nullptr;
     if (M > 0) {
         // per-column [min, max] of every `sub` rows: lets a wave skip sub-chunks none of its experts can select from
@@ -526,8 +610,8 @@ int gpsat_select_batch(gpsat_handle* h, const gpsat_select_spec* sp, int64_t M, 
         for (int cc = 0; cc < n_chunks; ++cc) { const long long v = cnt[(size_t)t * n_chunks + cc]; cnt[(size_t)t * n_chunks + cc] = run; run += v; }
     }
     off[T] = run;
-    if (!idx) return GPSAT_OK;
-    if (capacity < off[T]) return fail(GPSAT_EINVAL, "gpsat_select_batch: idx capacity too small (see off[T])");
+    if (idx && capacity < off[T]) return fail(GPSAT_EINVAL, "gpsat_select_batch: idx capacity too small (see off[T])");
+    const int* d_final = nullptr;
     if (off[T] > 0) {
         if ((rc = h->sel_idx.reserve((size_t)off[T] * sizeof(int)))) return rc;
         long long* d_off = static_cast<long long*>(h->sel_cnt.p) + ncell;
@@ -535,8 +619,26 @@ int gpsat_select_batch(gpsat_handle* h, const gpsat_select_spec* sp, int64_t M, 
         a.off = d_off;
         a.idx = static_cast<int*>(h->sel_idx.p);
         HIP_TRY(gpsat::launch_select(a, true, h->stream));
+        const int* d_result = a.idx;
+        if (d_perm) {
+            // positions of the binned table -> source rows, every expert's list ascending (source row order)
+            if (off[T] > 2147483647LL) return fail(GPSAT_EINVAL, "gpsat_select_batch: more than 2^31-1 selected rows");
+            std::vector<unsigned> off32(T + 1);
+            for (int t = 0; t <= T; ++t) off32[t] = (unsigned)off[t];
+            unsigned* d_off32 = reinterpret_cast<unsigned*>(static_cast<char*>(h->sel_ord.p) + (size_t)T * sizeof(int));
+            HIP_TRY(hipMemcpyAsync(d_off32, off32.data(), (size_t)(T + 1) * sizeof(unsigned), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if ((rc = h->sel_keys.reserve(std::max((size_t)M * 2 * sizeof(unsigned), (size_t)off[T] * sizeof(int))))) return rc;
+            int* d_sorted = static_cast<int*>(h->sel_keys.p);            // the row keys are no longer needed
+            size_t tb = 0;
+            HIP_TRY(gpsat::select_unbin(T, off[T], d_off32, d_perm, a.idx, d_sorted, nullptr, tb, h->stream));
+            if ((rc = h->sel_tmp.reserve(std::max<size_t>(tb, 16)))) return rc;
+            HIP_TRY(gpsat::select_unbin(T, off[T], d_off32, d_perm, a.idx, d_sorted, h->sel_tmp.p, tb, h->stream));
+            d_result = d_sorted;
+        }
         HIP_TRY(hipEventRecord(h->ev[2], h->stream));
-        HIP_TRY(hipMemcpyAsync(idx, a.idx, (size_t)off[T] * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        d_final = d_result;
+        if (idx) HIP_TRY(hipMemcpyAsync(idx, d_result, (size_t)off[T] * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     } else {
         HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     }
@@ -547,6 +649,12 @@ int gpsat_select_batch(gpsat_handle* h, const gpsat_select_spec* sp, int64_t M, 
     HIP_TRY(hipEventElapsedTime(&tm, h->ev[0], h->ev[3]));
     h->last_kernel_ms = km;
     h->last_total_ms = tm;
+    if (!idx) {
+        // sizes asked for: the indices stay on the device for the call that follows with the same arguments
+        h->selc.pts = points; h->selc.refs = refs; h->selc.M = M; h->selc.C = C; h->selc.T = T; h->selc.sp = *sp;
+        h->selc.d_result = d_final; h->selc.total = off[T];
+        h->selc.off.assign(off, off + T + 1);
+    }
     return GPSAT_OK;
 }
 

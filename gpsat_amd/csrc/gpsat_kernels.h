@@ -98,11 +98,26 @@ struct SelectArgs {
     const long long* off;             // [T][n_chunks] start offsets (fill pass)
     int* idx;                         // [off[T]] (fill pass)
     const double* box;                // [ceil(M / sub)][C][2] per-column [min, max] of every sub-chunk of rows, or nullptr
+    const int* eorder;                // [T] order in which the experts are dealt to the waves (neighbours together), or nullptr
 };
 
 hipError_t launch_select(const SelectArgs& a, bool fill, hipStream_t stream);
 hipError_t launch_select_boxes(long long M, int C, const double* pts, double* box, hipStream_t stream);
 int select_sub_rows();      // rows per box; chunk_rows must be a multiple of it
+
+// Spatial binning of the point table (gpsat_select.hip): rows sorted by the cell of up to 3 columns, so that the boxes of
+// consecutive rows are tight whatever order the table came in.
+struct BinSpec {
+    int ndim;                         // binned columns (1..3)
+    int col[3];
+    double origin[3], inv_cell[3];
+    int ncell[3];
+};
+hipError_t select_bin_rows(long long M, int C, const double* pts, const BinSpec& b, unsigned* keys, unsigned* keys_out, int* rows,
+                           int* perm, double* pts_perm, void* temp, size_t& temp_bytes, hipStream_t stream);
+// selected positions of the binned table -> source rows, every expert's list ascending (the reference's source row order)
+hipError_t select_unbin(int T, long long total, const unsigned* seg_off, const int* perm, int* idx, int* idx_out, void* temp,
+                        size_t& temp_bytes, hipStream_t stream);
 
 #define GPSAT_GLUE_MAXVARS 4
 // post-processing (gpsat_post.hip); device pointers

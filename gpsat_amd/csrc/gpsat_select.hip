@@ -19,12 +19,23 @@
 // skip almost everything outside an expert's window; on randomly ordered rows nothing is skipped and the box read
 // costs 1.6 % more traffic.  Membership and output order are unchanged either way.
 //
+// Spatial binning.  Tables that are NOT ordered (and any table against 100 000 experts) are first sorted on the device by
+// the grid cell of the criteria's columns (select_bin_rows: cell key per row, rocPRIM radix sort, gather into a permuted
+// copy), so that every box of SEL_SUB consecutive rows is a small region and the skipping above works whatever order the
+// rows came in; experts are dealt to the waves in the order of their own cells, so that the 8 experts of a wave want the
+// same boxes.  The predicates run on the same fp64 values (membership unchanged bit for bit); the selected positions are
+// mapped back to source rows and every expert's list is sorted ascending (select_unbin: rocPRIM segmented radix sort) --
+// the reference's source row order (dataloader.py:2447).
+//
 // This is HBM/L2-bound streaming + integer compaction: no MFMA.  One wave owns EB experts and streams the point
 // columns (SoA, coalesced 512-B wave reads, L2/MALL-resident across experts); matches are compacted with
 // ballot / popcount / mbcnt, so no LDS and no barriers.  The rows are cut into chunks (grid.y) so that the launch
 // has >> 256 workgroups; two passes: count per (expert, chunk), host scan, fill.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 #include "gpsat_kernels.h"
 
 namespace gpsat {
@@ -79,7 +90,7 @@ template <bool FILL>
 __global__ void __launch_bounds__(SEL_NT) select_kernel(const SelectArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (SEL_NT / 64) + (threadIdx.x >> 6);
-    const int e0 = wave * SEL_EB;
+    const int e0 = wave * SEL_EB;          // position in the dealing order (a.eorder), not an expert id
     if (e0 >= a.T) return;
     // blockIdx.y = row chunk: rows [r_beg, r_end); counts / offsets are kept per (expert, chunk) so that the fill pass
     // of every chunk knows where its rows go and the output stays in source row order
@@ -90,9 +101,12 @@ __global__ void __launch_bounds__(SEL_NT) select_kernel(const SelectArgs a) {
     // per expert, per criterion: the right-hand side (1-D: ref + val; ball: r*r) -- wave-uniform
     double rhs[SEL_EB][GPSAT_SEL_MAXCRIT];
     double rc[SEL_EB][GPSAT_SEL_MAXCRIT][3];
+    int eid[SEL_EB];                       // the experts of this wave
+#pragma unroll
+    for (int e = 0; e < SEL_EB; ++e) eid[e] = a.eorder ? a.eorder[e0 + min(e, ne - 1)] : e0 + min(e, ne - 1);
 #pragma unroll
     for (int e = 0; e < SEL_EB; ++e) {
-        const int ee = e0 + min(e, ne - 1);
+        const int ee = eid[e];
 #pragma unroll
         for (int k = 0; k < GPSAT_SEL_MAXCRIT; ++k) {
             rhs[e][k] = 0.0;
@@ -109,7 +123,7 @@ __global__ void __launch_bounds__(SEL_NT) select_kernel(const SelectArgs a) {
     }
     long long cnt[SEL_EB];
 #pragma unroll
-    for (int e = 0; e < SEL_EB; ++e) cnt[e] = FILL ? a.off[(size_t)(e0 + min(e, ne - 1)) * a.n_chunks + ch] : 0;
+    for (int e = 0; e < SEL_EB; ++e) cnt[e] = FILL ? a.off[(size_t)eid[e] * a.n_chunks + ch] : 0;
     for (long long sbeg = r_beg; sbeg < r_end; sbeg += SEL_SUB) {
       // ---- can any of this wave's experts select a row of this sub-chunk?  (wave-uniform arithmetic on its box)
       if (a.box) {
@@ -187,7 +201,7 @@ __global__ void __launch_bounds__(SEL_NT) select_kernel(const SelectArgs a) {
     if (!FILL && lane == 0) {
 #pragma unroll
         for (int e = 0; e < SEL_EB; ++e)
-            if (e < ne) a.counts[(size_t)(e0 + e) * a.n_chunks + ch] = cnt[e];
+            if (e < ne) a.counts[(size_t)eid[e] * a.n_chunks + ch] = cnt[e];
     }
 }
 
@@ -198,6 +212,60 @@ hipError_t launch_select_boxes(long long M, int C, const double* pts, double* bo
 }
 
 int select_sub_rows() { return SEL_SUB; }
+
+// ---- spatial binning -------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) select_key_kernel(long long M, const double* __restrict__ pts, BinSpec b, unsigned* __restrict__ keys,
+                                                         int* __restrict__ rows) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    unsigned key = 0;
+    for (int d = 0; d < b.ndim; ++d) {
+        const double x = pts[(size_t)b.col[d] * M + i];
+        double cf = (x - b.origin[d]) * b.inv_cell[d];
+        int cell = (cf >= 0.0) ? (int)fmin(cf, (double)(b.ncell[d] - 1)) : 0;       // NaN -> 0 (a NaN row matches nothing)
+        key = key * (unsigned)b.ncell[d] + (unsigned)cell;
+    }
+    keys[i] = key;
+    rows[i] = (int)i;
+}
+
+__global__ void __launch_bounds__(256) select_gather_kernel(long long M, int C, const double* __restrict__ pts, const int* __restrict__ perm,
+                                                            double* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int src = perm[i];
+    for (int c = 0; c < C; ++c) out[(size_t)c * M + i] = pts[(size_t)c * M + src];
+}
+
+__global__ void __launch_bounds__(256) select_map_kernel(long long n, const int* __restrict__ perm, int* __restrict__ idx) {
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (j < n) idx[j] = perm[idx[j]];
+}
+
+// temp == nullptr: only the size of the temporary storage is returned in temp_bytes
+hipError_t select_bin_rows(long long M, int C, const double* pts, const BinSpec& b, unsigned* keys, unsigned* keys_out, int* rows,
+                           int* perm, double* pts_perm, void* temp, size_t& temp_bytes, hipStream_t stream) {
+    unsigned long long cells = 1;
+    for (int d = 0; d < b.ndim; ++d) cells *= (unsigned long long)b.ncell[d];
+    int bits = 1;
+    while ((1ull << bits) < cells) ++bits;
+    if (!temp) return rocprim::radix_sort_pairs(nullptr, temp_bytes, keys, keys_out, rows, perm, (size_t)M, 0, bits, stream);
+    const unsigned grid = (unsigned)((M + 255) / 256);
+    hipLaunchKernelGGL(select_key_kernel, dim3(grid), dim3(256), 0, stream, M, pts, b, keys, rows);
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_out, rows, perm, (size_t)M, 0, bits, stream);   // stable
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(select_gather_kernel, dim3(grid), dim3(256), 0, stream, M, C, pts, perm, pts_perm);
+    return hipGetLastError();
+}
+
+hipError_t select_unbin(int T, long long total, const unsigned* seg_off, const int* perm, int* idx, int* idx_out, void* temp,
+                        size_t& temp_bytes, hipStream_t stream) {
+    if (!temp) return rocprim::segmented_radix_sort_keys(nullptr, temp_bytes, idx, idx_out, (unsigned)total, (unsigned)T, seg_off,
+                                                         seg_off + 1, 0, 32, stream);
+    hipLaunchKernelGGL(select_map_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, total, perm, idx);
+    return rocprim::segmented_radix_sort_keys(temp, temp_bytes, idx, idx_out, (unsigned)total, (unsigned)T, seg_off, seg_off + 1, 0, 32,
+                                              stream);
+}
 
 hipError_t launch_select(const SelectArgs& a, bool fill, hipStream_t stream) {
     const int waves = (a.T + SEL_EB - 1) / SEL_EB;

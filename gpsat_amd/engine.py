@@ -188,19 +188,23 @@ class Engine:
                            f_cov=(fc[:int(cov_off[-1])] if full_cov else None), cov_off=cov_off)
 
 
-    def select_batch(self, points: np.ndarray, refs: np.ndarray, criteria):
+    def select_batch(self, points: np.ndarray, refs: np.ndarray, criteria, points_cm: np.ndarray = None):
         """Batched tile selection on the GPU (gpsat_select_batch).
 
         points [M, C] fp64, refs [T, C] fp64 (same column numbering); criteria: list of
         ("cmp", col, comp, val)  ->  points[:, col] <comp> refs[:, col] + val
         ("ball", [cols], comp, r) -> Euclidean ball, comp "<=" (inclusive) or "<" (strict).
         Returns (off [T+1] int64, idx [off[-1]] int32): selected rows per expert in source order."""
-        points = np.asarray(points, dtype=np.float64)
         refs = np.ascontiguousarray(refs, dtype=np.float64)
-        M, Cc = points.shape
         T = refs.shape[0]
+        if points_cm is not None:                                      # the table already column-major [C][M] (kept by the caller)
+            pts_cm = np.ascontiguousarray(points_cm, dtype=np.float64)
+            Cc, M = pts_cm.shape
+        else:
+            points = np.asarray(points, dtype=np.float64)
+            M, Cc = points.shape
+            pts_cm = np.ascontiguousarray(points.T)                   # column-major [C][M]
         assert refs.shape[1] == Cc
-        pts_cm = np.ascontiguousarray(points.T)                       # column-major [C][M]
         sp = L.GpsatSelectSpec()
         if not 1 <= len(criteria) <= L.SEL_MAXCRIT:
             raise GpsatError(f"1..{L.SEL_MAXCRIT} criteria supported")

@@ -168,6 +168,7 @@ class DeviceSelector:
                     cols.append(c_)
         self.cols = cols
         self.points = df.loc[:, cols].values.astype(np.float64)
+        self.points_cm = np.ascontiguousarray(self.points.T)          # what the C ABI takes: column-major, made once
         self.criteria = []
         for ls in local_select:
             if isinstance(ls["col"], str):
@@ -184,7 +185,8 @@ class DeviceSelector:
         Returns CSR (off [T+1], idx [off[-1]]) of selected row POSITIONS of the frame, ascending per expert."""
         for c_ in self.cols:
             assert c_ in refs, f"col: {c_} is not in reference_location - {list(refs.columns)}"
-        return self.engine.select_batch(self.points, refs.loc[:, self.cols].values.astype(np.float64), self.criteria)
+        return self.engine.select_batch(None, refs.loc[:, self.cols].values.astype(np.float64), self.criteria,
+                                        points_cm=self.points_cm)
 
 
 def max_dist_bool(loc: np.ndarray, ref_loc: np.ndarray, max_dist: float) -> np.ndarray:

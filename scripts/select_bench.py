@@ -34,6 +34,17 @@ ds.select(xl1.iloc[:8])
 t0 = time.perf_counter(); off4, idx4 = ds.select(xl1); dt4 = time.perf_counter() - t0
 eng._lib.gpsat_last_timing(eng._h, C.byref(km), C.byref(tm))
 print(f"device, rows in random order, experts of one day: kernels {km.value:.1f} ms, {dt4*1e3:.1f} ms wall")
+if os.environ.get("BIG"):
+    # 100 000 experts x 10 M rows (was ~15 s without binning)
+    Mb, Tb = 10_000_000, 100_000
+    dfb = pd.DataFrame({"x": rng.uniform(-3e6, 3e6, Mb), "y": rng.uniform(-3e6, 3e6, Mb), "t": rng.integers(0, 30, Mb).astype(float)})
+    xlb = pd.DataFrame({"x": rng.uniform(-2.5e6, 2.5e6, Tb), "y": rng.uniform(-2.5e6, 2.5e6, Tb), "t": rng.integers(4, 26, Tb).astype(float)})
+    lsb = [{"col": "t", "comp": "<=", "val": 4}, {"col": "t", "comp": ">=", "val": -4}, {"col": ["x", "y"], "comp": "<", "val": 2.2e4}]
+    dsb = DeviceSelector(dfb, lsb, eng)
+    dsb.select(xlb.iloc[:8])
+    t0 = time.perf_counter(); offb, idxb = dsb.select(xlb); dtb = time.perf_counter() - t0
+    eng._lib.gpsat_last_timing(eng._h, C.byref(km), C.byref(tm))
+    print(f"device, binned: T={Tb} M={Mb}: {dtb*1e3:.0f} ms wall (device part {tm.value:.0f} ms), mean N/tile {offb[-1]/Tb:.0f}")
 hs = LocalSelector(df, ls)
 t0 = time.perf_counter()
 for t in range(64):
