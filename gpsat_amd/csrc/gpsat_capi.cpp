@@ -226,7 +226,9 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     if ((rc = h->out_i32.reserve((size_t)T * 3 * sizeof(int)))) return rc;
     // fp32: two 4-wave workgroups per CU while a workgroup's LDS fits twice; beyond that one 8-wave workgroup per CU
     // (the 8-wave build of the same kernels), so that every SIMD still has two waves to overlap
-    const bool w8 = !f64 && (gpsat::shared_bytes(D, NBmax) > 80 * 1024 || h->wg_per_cu == 1);
+    // ... and launches with fewer tiles than CUs: every tile has a CU to itself, eight waves use it better than four, and
+    // the 8-wave build is the one with cooperative tiles
+    const bool w8 = !f64 && (gpsat::shared_bytes(D, NBmax) > 80 * 1024 || h->wg_per_cu == 1 || T < h->num_cu);
     // fp64: the same rule with the 4-wave / 8-wave builds of the fp64 kernels
     const bool d4 = f64 && gpsat::shared_bytes_f64_w4(D, NBmax) <= 80 * 1024 && h->wg_per_cu != 1;
     const size_t wsf = f64 ? (d4 ? gpsat::workspace_doubles_per_wg_f64_w4(NBmax, PCcov) : gpsat::workspace_doubles_per_wg_f64(NBmax, PCcov))
@@ -256,9 +258,9 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     if (const char* e = std::getenv("GPSAT_DEBUG_COOP_HDIV")) coop_hdiv = std::max(1, std::atoi(e));
     // Helpers must be capacity that would otherwise idle.  8-wave build: one workgroup per CU, a workgroup without a tile
     // leaves its CU empty -- always on.  4-wave build (two workgroups per CU): an idle workgroup's CU-mate already runs 1.4 x
-    // faster alone, and a helper takes that back (measured on BASELINE configs[1]: the helped tail is 2 % SLOWER) -- on only
-    // while the launch has fewer tiles than CUs, widened to at most one workgroup per CU.
-    if (coop && !w8 && T >= h->num_cu) coop = false;
+    // faster alone, and a helper takes that back (measured on BASELINE configs[1]: the helped tail is 2 % SLOWER) -- off; a
+    // launch with fewer tiles than CUs runs the 8-wave build anyway, widened to at most one workgroup per CU.
+    if (coop && !w8) coop = false;
     if (coop) {
         const int cap = h->num_cu;
         long long want = grid;

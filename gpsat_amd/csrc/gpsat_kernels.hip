@@ -1749,7 +1749,11 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
     if (c.w == 0) { stg(c.ws, c.zb, c.lane, zero16()); coop_drain(); }     // (read behind the barrier at the top of the tile loop)
     // cooperative tiles: this workgroup's control block (as an owner); z and alpha of a cooperative evaluation live in
     // the 8 blocks in front of the zero block
-    const bool coop_on = A.coop != nullptr;
+    // Cooperative tiles are compiled into the 8-wave build only: the 4-wave build runs two workgroups per CU, where a helper
+    // gives nothing, and without the two out-of-line call sites its tile loop keeps half as many
+    // registers in scratch.  Launches with fewer tiles than CUs take the 8-wave build (gpsat_capi.cpp).
+    constexpr bool COOP_BUILD = (NW == 8);
+    const bool coop_on = COOP_BUILD && A.coop != nullptr;
     gCoopCtl* const ctl_own = as_gctl(A.coop) + blockIdx.x;       // dereferenced only when coop_on
     if (c.tid == 0) { sh->hp[0] = -1; sh->hp[1] = -1; sh->hp[2] = -1; sh->coop_now = 0; sh->coop_seq = 0; }
     c.prof = sh->prof;
