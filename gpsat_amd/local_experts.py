@@ -897,82 +897,93 @@ class BatchedLocalExpertOI:
                 tables = tables_for(items, fixed, pred_cat, cov_cat)
                 self.timings["tables_s"] += time.perf_counter() - tt
                 tf = time.perf_counter()
-                shard_store.write_wave(tables)                        # commit: these experts are done
+                # commit: these experts are done.  The parts are written by a helper thread while the next wave runs (one
+                # writer, waves in order, marker last); a flush that fails surfaces when the next one is queued or at the end
+                if pending:
+                    pending.pop().result()
+                pending.append(flusher.submit(shard_store.write_wave, tables))
                 self.timings["flush_s"] += time.perf_counter() - tf
                 fixed_rows.append(fixed)
                 pred_rows.append(pred_cat)
                 if want_cov:
                     cov_rows.append(cov_cat)
 
-            with ThreadPoolExecutor(max_workers=1) as pool:
-                nxt = pool.submit(pack_job, waves[jobs[0][0]][jobs[0][2]], jobs[0][1]) if jobs else None
-                done_waves = 0
-                for k, (wi, pi, loc_ids) in enumerate(jobs):
-                    while done_waves < wi:                            # waves without a single model tile (stubs, errors only)
+            pending = []
+            with ThreadPoolExecutor(max_workers=1) as pool, ThreadPoolExecutor(max_workers=1) as flusher:
+                try:
+                    nxt = pool.submit(pack_job, waves[jobs[0][0]][jobs[0][2]], jobs[0][1]) if jobs else None
+                    done_waves = 0
+                    for k, (wi, pi, loc_ids) in enumerate(jobs):
+                        while done_waves < wi:                            # waves without a single model tile (stubs, errors only)
+                            if done_waves not in state:
+                                open_wave(done_waves)
+                            close_wave(done_waves)
+                            done_waves += 1
+                        if wi not in state:
+                            open_wave(wi)
+                        fixed, preds, covs = state[wi]
+                        ids = waves[wi][loc_ids]
+                        te = time.perf_counter()
+                        pk = nxt.result()
+                        self.timings["pack_wait_s"] += time.perf_counter() - te
+                        if k + 1 < len(jobs):
+                            nxt = pool.submit(pack_job, waves[jobs[k + 1][0]][jobs[k + 1][2]], jobs[k + 1][1])
+                        t_, p_ = tmpl[pi], pinfo[pi]
+                        th_call = theta0[ids]
+                        if self.use_previous:
+                            if prev["theta"] is None:
+                                prev["theta"] = t_["theta_default"].copy()
+                            th_call = np.tile(prev["theta"], (len(ids), 1))
+                            for sl, tol in t_["clamp"]:                   # set_parameters(prev), then the constraints' clamp
+                                th_call[:, sl] = clamp_within(th_call[:, sl], t_["lo"][sl], t_["hi"][sl], tol)
+                        te = time.perf_counter()
+                        r = self.engine.fit_predict_batch(D=D, obs_off=pk["o_off"], X=pk["X"], y=pk["y"], pred_off=pk["p_off"],
+                                                          Xs=pk["Xs"], theta0=th_call, lo=lo[ids], hi=hi[ids],
+                                                          trainable=t_["trainable"], kernel=p_["kernel"],
+                                                          optimiser=p_["optimiser"], max_iter=p_["max_iter"],
+                                                          dtype=self.dtype, **p_["eng_kw"],
+                                                          **({"full_cov": True} if p_["full_cov"] else {}))
+                        if self.use_previous and p_["optimiser"] != "none":
+                            for kk in range(len(ids)):                    # expert order; only successful optimisations, no NaN
+                                if r.status[kk] == 0 and save_params[ids[kk]] and not np.isnan(r.theta[kk]).any():
+                                    prev["theta"] = 0.95 * prev["theta"] + 0.05 * r.theta[kk]
+                        dt = (time.perf_counter() - te) / len(ids)
+                        self.timings["engine_s"] += time.perf_counter() - te
+                        fixed[loc_ids, :H] = r.theta
+                        fixed[loc_ids, H] = r.nll
+                        fixed[loc_ids, H + 1] = r.status
+                        fixed[loc_ids, H + 2] = r.n_eval
+                        fixed[loc_ids, H + 3] = r.n_iter if getattr(r, "n_iter", None) is not None else np.nan
+                        fixed[loc_ids, H + 4] = dt
+                        fixed[loc_ids, H + 5] = pk["mean"]
+                        if predict:
+                            pr = np.stack([np.asarray(r.f_mean, dtype=np.float64), np.asarray(r.f_var, dtype=np.float64),
+                                           np.asarray(r.y_var, dtype=np.float64)], axis=1)
+                            p_off = pk["p_off"]
+                            for kk, j in enumerate(loc_ids):
+                                preds[j] = pr[p_off[kk]:p_off[kk + 1]]
+                            if p_["full_cov"]:
+                                fc = np.asarray(r.f_cov, dtype=np.float64)
+                                for kk, j in enumerate(loc_ids):
+                                    P_ = int(p_off[kk + 1] - p_off[kk])
+                                    fcov = fc[r.cov_off[kk]:r.cov_off[kk + 1]].reshape(P_, P_)
+                                    ycov = fcov.copy()                     # y_cov = f*_cov + diag(y_var - f*_var), gpflow_models.py:250-254
+                                    seg = pr[p_off[kk]:p_off[kk + 1]]
+                                    ycov[np.arange(P_), np.arange(P_)] += seg[:, 2] - seg[:, 1]
+                                    covs[j] = np.stack([fcov.reshape(-1), ycov.reshape(-1)], axis=1)
+                        if last_job_of_wave[wi] == k:
+                            close_wave(wi)
+                            done_waves = wi + 1
+                    while done_waves < len(waves):
                         if done_waves not in state:
                             open_wave(done_waves)
                         close_wave(done_waves)
                         done_waves += 1
-                    if wi not in state:
-                        open_wave(wi)
-                    fixed, preds, covs = state[wi]
-                    ids = waves[wi][loc_ids]
-                    te = time.perf_counter()
-                    pk = nxt.result()
-                    self.timings["pack_wait_s"] += time.perf_counter() - te
-                    if k + 1 < len(jobs):
-                        nxt = pool.submit(pack_job, waves[jobs[k + 1][0]][jobs[k + 1][2]], jobs[k + 1][1])
-                    t_, p_ = tmpl[pi], pinfo[pi]
-                    th_call = theta0[ids]
-                    if self.use_previous:
-                        if prev["theta"] is None:
-                            prev["theta"] = t_["theta_default"].copy()
-                        th_call = np.tile(prev["theta"], (len(ids), 1))
-                        for sl, tol in t_["clamp"]:                   # set_parameters(prev), then the constraints' clamp
-                            th_call[:, sl] = clamp_within(th_call[:, sl], t_["lo"][sl], t_["hi"][sl], tol)
-                    te = time.perf_counter()
-                    r = self.engine.fit_predict_batch(D=D, obs_off=pk["o_off"], X=pk["X"], y=pk["y"], pred_off=pk["p_off"],
-                                                      Xs=pk["Xs"], theta0=th_call, lo=lo[ids], hi=hi[ids],
-                                                      trainable=t_["trainable"], kernel=p_["kernel"],
-                                                      optimiser=p_["optimiser"], max_iter=p_["max_iter"],
-                                                      dtype=self.dtype, **p_["eng_kw"],
-                                                      **({"full_cov": True} if p_["full_cov"] else {}))
-                    if self.use_previous and p_["optimiser"] != "none":
-                        for kk in range(len(ids)):                    # expert order; only successful optimisations, no NaN
-                            if r.status[kk] == 0 and save_params[ids[kk]] and not np.isnan(r.theta[kk]).any():
-                                prev["theta"] = 0.95 * prev["theta"] + 0.05 * r.theta[kk]
-                    dt = (time.perf_counter() - te) / len(ids)
-                    self.timings["engine_s"] += time.perf_counter() - te
-                    fixed[loc_ids, :H] = r.theta
-                    fixed[loc_ids, H] = r.nll
-                    fixed[loc_ids, H + 1] = r.status
-                    fixed[loc_ids, H + 2] = r.n_eval
-                    fixed[loc_ids, H + 3] = r.n_iter if getattr(r, "n_iter", None) is not None else np.nan
-                    fixed[loc_ids, H + 4] = dt
-                    fixed[loc_ids, H + 5] = pk["mean"]
-                    if predict:
-                        pr = np.stack([np.asarray(r.f_mean, dtype=np.float64), np.asarray(r.f_var, dtype=np.float64),
-                                       np.asarray(r.y_var, dtype=np.float64)], axis=1)
-                        p_off = pk["p_off"]
-                        for kk, j in enumerate(loc_ids):
-                            preds[j] = pr[p_off[kk]:p_off[kk + 1]]
-                        if p_["full_cov"]:
-                            fc = np.asarray(r.f_cov, dtype=np.float64)
-                            for kk, j in enumerate(loc_ids):
-                                P_ = int(p_off[kk + 1] - p_off[kk])
-                                fcov = fc[r.cov_off[kk]:r.cov_off[kk + 1]].reshape(P_, P_)
-                                ycov = fcov.copy()                     # y_cov = f*_cov + diag(y_var - f*_var), gpflow_models.py:250-254
-                                seg = pr[p_off[kk]:p_off[kk + 1]]
-                                ycov[np.arange(P_), np.arange(P_)] += seg[:, 2] - seg[:, 1]
-                                covs[j] = np.stack([fcov.reshape(-1), ycov.reshape(-1)], axis=1)
-                    if last_job_of_wave[wi] == k:
-                        close_wave(wi)
-                        done_waves = wi + 1
-                while done_waves < len(waves):
-                    if done_waves not in state:
-                        open_wave(done_waves)
-                    close_wave(done_waves)
-                    done_waves += 1
+                finally:
+                    # the last queued flush (and, after a fault, the one of the last complete wave) is on disk before this
+                    # returns or the fault propagates: a committed wave survives whatever happens to the next one
+                    while pending:
+                        pending.pop().result()
             fixed_all = np.concatenate(fixed_rows) if fixed_rows else np.zeros((0, H + 6))
             preds_all = np.concatenate(pred_rows) if pred_rows else np.zeros((0, 3))
             cnt = np.where(kind[mine] == 2, n_pred[mine] if predict else 0, 0).astype(np.int64)

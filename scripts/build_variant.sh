@@ -12,7 +12,7 @@ cd "$ROOT"
 if [ -n "$PATCH" ]; then patch -p1 < "$PATCH"; trap 'cd "$ROOT" && patch -R -p1 < "$PATCH"' EXIT; fi
 cd "$ROOT/gpsat_amd/csrc"
 F="-O3 -std=c++17 -fPIC -ffp-contract=on --offload-arch=gfx950 -I../../include -I. -Wno-unused-function"
-/opt/rocm/bin/hipcc $F "$@" -c gpsat_kernels.hip -o /tmp/v_${TAG}_k.o &
+/opt/rocm/bin/hipcc $F -ffp-contract=fast "$@" -c gpsat_kernels.hip -o /tmp/v_${TAG}_k.o &
 /opt/rocm/bin/hipcc $F "$@" -DGPSAT_W8 -c gpsat_kernels.hip -o /tmp/v_${TAG}_k8.o &
 /opt/rocm/bin/hipcc $F "$@" -x hip -c gpsat_capi.cpp -o /tmp/v_${TAG}_capi.o &
 wait
