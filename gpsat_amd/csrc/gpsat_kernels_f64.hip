@@ -143,7 +143,7 @@ __device__ __forceinline__ void kfun(double r2, double& kf, double& gg) {
     }
 }
 
-struct Lay { int xsc, y, z, alpha, Ad, LT, tmp, Pn, tp4; };   // double offsets into lds_d
+struct Lay { int xsc, y, z, alpha, Ad, LT, tmp, Pn, tp4, PnLA, tpLA; };   // double offsets into lds_d
 
 // ---------------------------------------------------------------------------------------------
 // Teams (large fp64 tiles): G workgroups run ONE tile together, bulk-synchronously -- the kernel's phases as they are, every
@@ -347,6 +347,70 @@ __device__ __forceinline__ void diag_factor(const f64x4& W, int Ad, int lane, f6
 constexpr int PR = 4;
 __device__ __forceinline__ constexpr int pidx(int r, int r2) { return r * PR - (r * (r - 1)) / 2 + (r2 - r); }   // r <= r2 < 4
 
+// acc += sum_{k in [kb, ke)} U_k,jb+r^T U_k,jb+r2 ;  tp += the lane's share of sum_k U_k,jb+r^T z_k (diagonal items).
+// One product per step: the loop runs at the latency of its loads unless several steps are in flight.  A ring of PF operand
+// pairs (the tail reloads the last pair, unused) keeps PF steps of loads outstanding; the products are issued in ascending k.
+template <int D, int KN, bool TEAM>
+__device__ __forceinline__ void diag_chain(const Ctx<D, KN>& c, int jb, int r, int r2, int kb, int ke, bool dg, f64x4& acc, double& tp) {
+    if (kb >= ke) return;
+    const int NB = c.NB, lane = c.lane;
+    constexpr int PF = 6;
+    f64x4 Ar[PF], Br[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int kk = min(kb + u, ke - 1);
+        Ar[u] = ldg(c.ws, kk * NB + jb + r, lane);
+        Br[u] = ldg(c.ws, kk * NB + jb + r2, lane);
+    }
+    for (int k0 = kb; k0 < ke; k0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int k = k0 + u;
+            if (k < ke) {
+                mma_blk(acc, Ar[u], Br[u]);
+                if (dg) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) tp = fma(Ar[u][rr], lds_d[c.L.z + BS * k + rowof(rr, c.q)], tp);
+                }
+                const int kn = min(k + PF, ke - 1);
+                Ar[u] = ldg(c.ws, kn * NB + jb + r, lane);
+                Br[u] = ldg(c.ws, kn * NB + jb + r2, lane);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void diag_item(int bb, int& r, int& r2) {
+    r = 0; r2 = bb;
+    if (bb >= 9) { r = 3; r2 = 3; } else if (bb >= 7) { r = 2; r2 = bb - 5; } else if (bb >= 4) { r = 1; r2 = bb - 3; }
+}
+
+// Look-ahead (4-wave build, one workgroup per tile): the diagonal region of the NEXT panel summed over the rows of all panels
+// before the current one -- everything it needs is in memory when the current panel starts -- kept per lane in LDS (the
+// accumulator and the partial t, exactly: the next panel continues the same sums with the current panel's four rows).  These ten
+// chains are pulled by the waves that would otherwise wait for wave 0's serial part (B), and by every wave that runs out of
+// columns in (C); what is left of (A) is four steps per item.
+template <int D, int KN>
+__device__ __forceinline__ void la_items(const Ctx<D, KN>& c, int j0, int jn, bool until_b_done) {
+    Shared* sh = reinterpret_cast<Shared*>(lds_d);
+    const int nrn = min(PR, c.NB - jn);
+    for (;;) {
+        if (until_b_done && __hip_atomic_load(&sh->g0done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+        int v = 0;
+        if (c.lane == 0) v = atomicAdd(&sh->gnext[0], 1);
+        const int bb = __builtin_amdgcn_readfirstlane(v);
+        if (bb >= 10) break;
+        int r, r2;
+        diag_item(bb, r, r2);
+        if (r2 >= nrn) continue;
+        f64x4 acc = zero4();
+        double tp = 0.0;
+        diag_chain<D, KN, false>(c, jn, r, r2, 0, j0, r == r2, acc, tp);
+        stl(c.L.PnLA + bb * BLK, c.lane, acc);
+        if (r == r2) lds_d[c.L.tpLA + 64 * r + c.lane] = tp;
+    }
+}
+
 template <int D, int KN, bool TEAM>
 __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
     Shared* sh = reinterpret_cast<Shared*>(lds_d);
@@ -358,42 +422,22 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
         const int nr = min(PR, NB - j0);
         if (TEAM) t0 = __builtin_amdgcn_s_memtime();
         // ---- (A) diagonal region: D_rr' = K_jr,jr' - sum_{k<j0} U_k,jr^T U_k,jr'  and  t_r = sum_{k<j0} U_k,jr^T z_k
+        constexpr bool LA = !TEAM && (NW == 4);            // look-ahead of the next panel's diagonal region (la_items)
+        if (LA && c.tid == 0) { sh->gnext[0] = (j0 + PR < NB) ? 0 : 10; sh->g0done = 0; }
         for (int bb = c.vw; bb < 10; bb += c.nwt) {
-            int r = 0, r2 = bb;
-            if (bb >= 9) { r = 3; r2 = 3; } else if (bb >= 7) { r = 2; r2 = bb - 5; } else if (bb >= 4) { r = 1; r2 = bb - 3; }
+            int r, r2;
+            diag_item(bb, r, r2);
             if (r2 >= nr) continue;
             const bool dg = (r == r2);
             f64x4 acc = zero4();
             double tp = 0.0;
-            if (j0 > 0) {
-                // One product per step: the loop runs at the latency of its loads unless several steps are in flight.  A ring
-                // of PF operand pairs (the tail reloads the last pair, unused) keeps PF steps of loads outstanding; the
-                // products are issued in the same order as ever.  (With one step in flight this phase -- ten chains per panel,
-                // everybody else waiting -- was 6 of the 16 ms a team could not shorten in an N = 2500 evaluation.)
-                constexpr int PF = 6;
-                f64x4 Ar[PF], Br[PF];
-#pragma unroll
-                for (int u = 0; u < PF; ++u) {
-                    const int kk = min(u, j0 - 1);
-                    Ar[u] = ldg(c.ws, kk * NB + j0 + r, lane);
-                    Br[u] = ldg(c.ws, kk * NB + j0 + r2, lane);
-                }
-                for (int k0 = 0; k0 < j0; k0 += PF) {
-#pragma unroll
-                    for (int u = 0; u < PF; ++u) {
-                        const int k = k0 + u;
-                        if (k < j0) {
-                            mma_blk(acc, Ar[u], Br[u]);
-                            if (dg) {
-#pragma unroll
-                                for (int rr = 0; rr < 4; ++rr) tp = fma(Ar[u][rr], lds_d[c.L.z + BS * k + rowof(rr, c.q)], tp);
-                            }
-                            const int kn = min(k + PF, j0 - 1);
-                            Ar[u] = ldg(c.ws, kn * NB + j0 + r, lane);
-                            Br[u] = ldg(c.ws, kn * NB + j0 + r2, lane);
-                        }
-                    }
-                }
+            if (LA && j0 > 0) {
+                // rows of the panels before the previous one: summed ahead (la_items); the previous panel's rows now
+                acc = ldl(c.L.PnLA + bb * BLK, lane);
+                if (dg) tp = lds_d[c.L.tpLA + 64 * r + lane];
+                diag_chain<D, KN, TEAM>(c, j0, r, r2, j0 - PR, j0, dg, acc, tp);
+            } else {
+                diag_chain<D, KN, TEAM>(c, j0, r, r2, 0, j0, dg, acc, tp);
             }
             acc = kblock<D, KN>(c, j0 + r, j0 + r2) - acc;
             if (TEAM) stg(c.ws, c.pn0 + bb, lane, acc);
@@ -411,6 +455,7 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
         if (TEAM) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tA += t1 - t0; t0 = t1; }
         // ---- (B) the 4 x 4 block triangle (wave 0 of the owner): after it slot (r,r) of Pn holds (L_r^-1)^T, slot (r,r')
         // holds U_jr,jr'
+        if (LA && w != 0) la_items<D, KN>(c, j0, j0 + PR, true);
         if (w == 0 && c.member == 0) {
             f64x4 Dd[10];
 #pragma unroll
@@ -470,6 +515,7 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
                     }
                 }
             }
+            if (LA && lane == 0) __hip_atomic_store(&sh->g0done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         team_barrier<TEAM>(c);
         if (TEAM) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tB += t1 - t0; t0 = t1; }
@@ -565,6 +611,7 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
                 }
             }
         }
+        if (LA) la_items<D, KN>(c, j0, j0 + PR, false);
         team_barrier<TEAM>(c);
         if (TEAM) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tC += t1 - t0; t0 = t1; }
     }
@@ -1002,6 +1049,11 @@ __global__ void __launch_bounds__(NT, F64_MIN_WG) gp_tile_kernel_f64(const Kerne
     c.L.tmp = off; off += 16;
     c.L.Pn = off; off += 10 * BLK;         // diagonal region of the current panel (phase_potrf)
     c.L.tp4 = off; off += 4 * BS;
+    c.L.PnLA = 0; c.L.tpLA = 0;
+#ifdef GPSAT_F64_W4
+    c.L.PnLA = off; off += 10 * BLK;       // look-ahead sums of the next panel's diagonal region (la_items)
+    c.L.tpLA = off; off += 4 * 64;
+#endif
     double* wsall = reinterpret_cast<double*>(A.ws);
     const size_t stride = A.ws_stride;                 // doubles per workgroup
     c.ws = wsall + (size_t)blockIdx.x * stride;
@@ -1185,6 +1237,7 @@ __global__ void __launch_bounds__(NT, 1) gp_team_kernel_f64(const KernelArgs A) 
     c.L.tmp = off; off += 16;
     c.L.Pn = off; off += 10 * BLK;
     c.L.tp4 = off; off += 4 * BS;
+    c.L.PnLA = 0; c.L.tpLA = 0;
     const int G = A.team_size;
     c.G = G;
     c.member = (int)blockIdx.x % G;
@@ -1385,7 +1438,10 @@ static hipError_t launch_d(const KernelArgs& a, int grid, size_t smem, hipStream
 
 size_t F64FN(shared_bytes_f64)(int D, int NBmax) {
     const size_t NP = (size_t)NBmax * F64NS::BS;
-    const size_t dbl = (sizeof(F64NS::Shared) + 15) / 16 * 2 + D * NP + 3 * NP + F64NS::BLK + 16 * 17 + 16 + 10 * F64NS::BLK + 4 * F64NS::BS + 2;
+    size_t dbl = (sizeof(F64NS::Shared) + 15) / 16 * 2 + D * NP + 3 * NP + F64NS::BLK + 16 * 17 + 16 + 10 * F64NS::BLK + 4 * F64NS::BS + 2;
+#ifdef GPSAT_F64_W4
+    dbl += 10 * F64NS::BLK + 4 * 64;       // look-ahead sums (la_items)
+#endif
     return (dbl * sizeof(double) + 15) & ~size_t(15);
 }
 
