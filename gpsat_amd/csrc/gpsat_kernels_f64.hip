@@ -200,8 +200,9 @@ struct Ctx {
 // Every wave has drained its stores, every workgroup of the team has arrived: data stored sc1 before the barrier is read
 // (sc1) behind it by any member.  One workgroup (G == 1): a plain workgroup barrier.  A barrier that gives up (never by
 // design; bounded so that a lost workgroup cannot hang the GPU) marks the evaluation failed.
+// `long_wait`: the command barrier, at which the members wait while the owner predicts (seconds for many prediction points).
 template <bool TEAM, int D, int KN>
-__device__ __forceinline__ void team_barrier(Ctx<D, KN>& c) {
+__device__ __forceinline__ void team_barrier(Ctx<D, KN>& c, bool long_wait = false) {
     if (!TEAM) { __syncthreads(); return; }
     Shared* sh = reinterpret_cast<Shared*>(lds_d);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -212,7 +213,8 @@ __device__ __forceinline__ void team_barrier(Ctx<D, KN>& c) {
         __hip_atomic_fetch_add(&c.tc->bar, 1, RLX_AGENT);
         for (int spins = 0; __hip_atomic_load(&c.tc->bar, RLX_AGENT) < target; ++spins) {
             __builtin_amdgcn_s_sleep(4);
-            if (spins > (1 << 23) || ((spins & 255) == 255 && __hip_atomic_load(&c.tc->timeout, RLX_AGENT))) {
+            if (long_wait && spins > (1 << 16)) __builtin_amdgcn_s_sleep(127);      // ~1 us per poll: minutes before it gives up
+            if (spins > (long_wait ? (1 << 27) : (1 << 23)) || ((spins & 255) == 255 && __hip_atomic_load(&c.tc->timeout, RLX_AGENT))) {
                 __hip_atomic_store(&c.tc->timeout, 1, RLX_AGENT);
                 break;
             }
@@ -385,7 +387,7 @@ __device__ __forceinline__ void diag_item(int bb, int& r, int& r2) {
     if (bb >= 9) { r = 3; r2 = 3; } else if (bb >= 7) { r = 2; r2 = bb - 5; } else if (bb >= 4) { r = 1; r2 = bb - 3; }
 }
 
-// Look-ahead (4-wave build, one workgroup per tile): the diagonal region of the NEXT panel summed over the rows of all panels
+// Look-ahead (one workgroup per tile): the diagonal region of the NEXT panel summed over the rows of all panels
 // before the current one -- everything it needs is in memory when the current panel starts -- kept per lane in LDS (the
 // accumulator and the partial t, exactly: the next panel continues the same sums with the current panel's four rows).  These ten
 // chains are pulled by the waves that would otherwise wait for wave 0's serial part (B), and by every wave that runs out of
@@ -406,8 +408,13 @@ __device__ __forceinline__ void la_items(const Ctx<D, KN>& c, int j0, int jn, bo
         f64x4 acc = zero4();
         double tp = 0.0;
         diag_chain<D, KN, false>(c, jn, r, r2, 0, j0, r == r2, acc, tp);
-        stl(c.L.PnLA + bb * BLK, c.lane, acc);
-        if (r == r2) lds_d[c.L.tpLA + 64 * r + c.lane] = tp;
+        if (NW == 4) {                                   // 4-wave build: LDS; 8-wave build (large tiles fill the LDS): workspace
+            stl(c.L.PnLA + bb * BLK, c.lane, acc);
+            if (r == r2) lds_d[c.L.tpLA + 64 * r + c.lane] = tp;
+        } else {
+            stg_t<false>(c.ws, c.pn0 + bb, c.lane, acc);
+            if (r == r2) c.ws[(size_t)(c.pn0 + 11) * BLK + 64 * r + c.lane] = tp;
+        }
     }
 }
 
@@ -422,7 +429,7 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
         const int nr = min(PR, NB - j0);
         if (TEAM) t0 = __builtin_amdgcn_s_memtime();
         // ---- (A) diagonal region: D_rr' = K_jr,jr' - sum_{k<j0} U_k,jr^T U_k,jr'  and  t_r = sum_{k<j0} U_k,jr^T z_k
-        constexpr bool LA = !TEAM && (NW == 4);            // look-ahead of the next panel's diagonal region (la_items)
+        constexpr bool LA = !TEAM;                         // look-ahead of the next panel's diagonal region (la_items)
         if (LA && c.tid == 0) { sh->gnext[0] = (j0 + PR < NB) ? 0 : 10; sh->g0done = 0; }
         for (int bb = c.vw; bb < 10; bb += c.nwt) {
             int r, r2;
@@ -433,8 +440,13 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
             double tp = 0.0;
             if (LA && j0 > 0) {
                 // rows of the panels before the previous one: summed ahead (la_items); the previous panel's rows now
-                acc = ldl(c.L.PnLA + bb * BLK, lane);
-                if (dg) tp = lds_d[c.L.tpLA + 64 * r + lane];
+                if (NW == 4) {
+                    acc = ldl(c.L.PnLA + bb * BLK, lane);
+                    if (dg) tp = lds_d[c.L.tpLA + 64 * r + lane];
+                } else {
+                    acc = ldg(c.ws, c.pn0 + bb, lane);
+                    if (dg) tp = c.ws[(size_t)(c.pn0 + 11) * BLK + 64 * r + lane];
+                }
                 diag_chain<D, KN, TEAM>(c, j0, r, r2, j0 - PR, j0, dg, acc, tp);
             } else {
                 diag_chain<D, KN, TEAM>(c, j0, r, r2, 0, j0, dg, acc, tp);
@@ -1059,7 +1071,8 @@ __global__ void __launch_bounds__(NT, F64_MIN_WG) gp_tile_kernel_f64(const Kerne
     c.ws = wsall + (size_t)blockIdx.x * stride;
     c.zb = (int)(stride / BLK) - 1;
     for (int i = c.tid; i < BLK; i += NT) c.ws[(size_t)c.zb * BLK + i] = 0.0;
-    c.vw = c.w; c.nwt = NW; c.member = 0; c.G = 1; c.tc = nullptr; c.pn0 = 0; c.tpg = nullptr; c.zg = nullptr; c.ag = nullptr;
+    c.vw = c.w; c.nwt = NW; c.member = 0; c.G = 1; c.tc = nullptr; c.tpg = nullptr; c.zg = nullptr; c.ag = nullptr;
+    c.pn0 = c.zb - 40;           // the exchange area of teams doubles as the look-ahead store of the 8-wave build
     const double* X = reinterpret_cast<const double*>(A.X);
     const double* y = reinterpret_cast<const double*>(A.y);
     const double* Xs = reinterpret_cast<const double*>(A.Xs);
@@ -1282,7 +1295,7 @@ __global__ void __launch_bounds__(NT, 1) gp_team_kernel_f64(const KernelArgs A) 
         // ---- a member: follow the owner's commands
         int t = -1;
         for (;;) {
-            team_barrier<TEAM>(c);                                         // the command barrier
+            team_barrier<TEAM>(c, true);                                   // the command barrier
             if (c.tid == 0) {
                 sh->hp[1] = __hip_atomic_load(&c.tc->cmd, RLX_AGENT);
                 sh->hp[2] = __hip_atomic_load(&c.tc->tile, RLX_AGENT);
@@ -1308,7 +1321,7 @@ __global__ void __launch_bounds__(NT, 1) gp_team_kernel_f64(const KernelArgs A) 
             __hip_atomic_store(&c.tc->fail, 0, RLX_AGENT);
             __hip_atomic_store(&c.tc->cmd, cmd, RLX_AGENT);
         }
-        team_barrier<TEAM>(c);
+        team_barrier<TEAM>(c, true);
     };
     for (;;) {
         __syncthreads();
