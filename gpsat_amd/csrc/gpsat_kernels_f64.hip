@@ -349,6 +349,126 @@ __device__ __forceinline__ void diag_factor(const f64x4& W, int Ad, int lane, f6
 constexpr int PR = 4;
 __device__ __forceinline__ constexpr int pidx(int r, int r2) { return r * PR - (r * (r - 1)) / 2 + (r2 - r); }   // r <= r2 < 4
 
+// ---- M = L^-1 (lower slots) and alpha = M^T z, the rows of ONE panel (i0 .. i0 + nr): called from the column phase of
+// phase_potrf, right behind the panel's serial part -- everything it reads is in memory by then (earlier panels' rows of U
+// and M, this panel's factors and in-panel U blocks, z) -- so that the inverse costs no barriers of its own and its items
+// fill the column phase of the late panels, where few U columns are left.  A wave owns pairs of block columns, 4 x 2
+// accumulators:   M_ij = -L_i^-1 sum_{k=j}^{i-1} U_ki^T M_kj   (M_jj = L_j^-1 already in the diagonal slot).
+// alpha: one writer per column and panel, panels separated by (team) barriers, so every column's sum keeps its order; a team
+// keeps alpha in its workspace.
+template <int D, int KN, bool TEAM>
+__device__ __forceinline__ void trtri_pair(Ctx<D, KN>& c, int i0, int nr, int p) {       // the column pair 2p, 2p + 1 < i0
+    const int NB = c.NB, lane = c.lane;
+    const int jc0 = 2 * p, jc1 = jc0 + 1;
+    f64x4 acc[PR][2];
+#pragma unroll
+    for (int r = 0; r < PR; ++r) { acc[r][0] = zero4(); acc[r][1] = zero4(); }
+    {
+        f64x4 A[PR], B0, B1;
+#pragma unroll
+        for (int r = 0; r < PR; ++r) A[r] = ldg(c.ws, (r < nr) ? jc0 * NB + i0 + r : c.zb, lane);
+        B0 = ldg(c.ws, jc0 * NB + jc0, lane);
+        B1 = ldg(c.ws, c.zb, lane);                         // M_k,jc1 is zero for k = jc0 < jc1
+        for (int k = jc0; k + 1 < i0; ++k) {          // last step peeled: unconditional loads, no copy-first
+            f64x4 nA[PR], nB0, nB1;
+#pragma unroll
+            for (int r = 0; r < PR; ++r) nA[r] = ldg(c.ws, (r < nr) ? (k + 1) * NB + i0 + r : c.zb, lane);
+            nB0 = ldg(c.ws, (k + 1) * NB + jc0, lane);
+            nB1 = ldg(c.ws, (k + 1) * NB + jc1, lane);
+#pragma unroll
+            for (int r = 0; r < PR; ++r) { mma_blk(acc[r][0], A[r], B0); mma_blk(acc[r][1], A[r], B1); }
+#pragma unroll
+            for (int r = 0; r < PR; ++r) A[r] = nA[r];
+            B0 = nB0; B1 = nB1;
+        }
+        if (jc0 < i0) {
+#pragma unroll
+            for (int r = 0; r < PR; ++r) { mma_blk(acc[r][0], A[r], B0); mma_blk(acc[r][1], A[r], B1); }
+        }
+    }
+    double ap0 = 0.0, ap1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+        if (r < nr) {
+            const int ir = i0 + r;
+            const f64x4 Lop = ldg(c.ws, c.dT0 + ir, lane);
+            f64x4 X0 = zero4(), X1 = zero4();
+            mma_blk(X0, Lop, acc[r][0]);
+            mma_blk(X1, Lop, acc[r][1]);
+            X0 = -X0; X1 = -X1;
+            stg(c.ws, ir * NB + jc0, lane, X0);
+            stg(c.ws, ir * NB + jc1, lane, X1);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const double zr = lds_d[c.L.z + BS * ir + rowof(rr, c.q)];
+                ap0 = fma(X0[rr], zr, ap0);
+                ap1 = fma(X1[rr], zr, ap1);
+            }
+#pragma unroll
+            for (int r2 = r + 1; r2 < PR; ++r2) {
+                if (r2 < nr) {
+                    const f64x4 U = ldg(c.ws, ir * NB + i0 + r2, lane);
+                    mma_blk(acc[r2][0], U, X0);
+                    mma_blk(acc[r2][1], U, X1);
+                }
+            }
+        }
+    }
+    ap0 = qsum(ap0); ap1 = qsum(ap1);
+    if (c.q == 0) {                              // a column pair always belongs to the same wave: no race
+        if (TEAM) {
+            gdouble *a0 = c.ag + BS * jc0 + c.g, *a1 = c.ag + BS * jc1 + c.g;
+            gst_d(a0, gld_d(a0) + ap0);
+            gst_d(a1, gld_d(a1) + ap1);
+        } else {
+            lds_d[c.L.alpha + BS * jc0 + c.g] += ap0;
+            lds_d[c.L.alpha + BS * jc1 + c.g] += ap1;
+        }
+    }
+}
+
+template <int D, int KN, bool TEAM>
+__device__ __forceinline__ void trtri_triangle(Ctx<D, KN>& c, int i0, int nr) {           // the triangle inside the panel
+    const int NB = c.NB, lane = c.lane;
+    for (int j = i0; j < i0 + nr; ++j) {
+        const f64x4 Mjj = ldg(c.ws, j * NB + j, lane);
+        double ap = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) ap = fma(Mjj[rr], lds_d[c.L.z + BS * j + rowof(rr, c.q)], ap);
+        for (int i = j + 1; i < i0 + nr; ++i) {
+            f64x4 acc = zero4();
+            for (int k = j; k < i; ++k) {
+                const f64x4 A = ldg(c.ws, k * NB + i, lane);        // U_ki
+                const f64x4 B = ldg(c.ws, k * NB + j, lane);        // M_kj (k == j: diagonal slot)
+                mma_blk(acc, A, B);
+            }
+            const f64x4 Lop = ldg(c.ws, c.dT0 + i, lane);
+            f64x4 Mij = zero4();
+            mma_blk(Mij, Lop, acc);
+            Mij = -Mij;
+            stg(c.ws, i * NB + j, lane, Mij);
+            // this wave reads the block back a few instructions later (k = i of the next row): a write-through store
+            // still on its way is not ordered before a load of the same bytes
+            if (TEAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) ap = fma(Mij[rr], lds_d[c.L.z + BS * i + rowof(rr, c.q)], ap);
+        }
+        const double a = qsum(ap);
+        if (c.q == 0) {
+            if (TEAM) { gdouble* aj = c.ag + BS * j + c.g; gst_d(aj, gld_d(aj) + a); }
+            else lds_d[c.L.alpha + BS * j + c.g] += a;
+        }
+    }
+}
+
+// static deal (teams): pairs from the last wave down -- the first waves have the most U columns of the panel, wave 0 its
+// serial part -- and the triangle on one wave
+template <int D, int KN, bool TEAM>
+__device__ __forceinline__ void trtri_panel(Ctx<D, KN>& c, int i0, int nr) {
+    for (int p = c.nwt - 1 - c.vw; 2 * p < i0; p += c.nwt) trtri_pair<D, KN, TEAM>(c, i0, nr, p);
+    if (c.vw == c.nwt - 1 - ((i0 >> 1) % c.nwt)) trtri_triangle<D, KN, TEAM>(c, i0, nr);
+}
+
 // acc += sum_{k in [kb, ke)} U_k,jb+r^T U_k,jb+r2 ;  tp += the lane's share of sum_k U_k,jb+r^T z_k (diagonal items).
 // One product per step: the loop runs at the latency of its loads unless several steps are in flight.  A ring of PF operand
 // pairs (the tail reloads the last pair, unused) keeps PF steps of loads outstanding; the products are issued in ascending k.
@@ -419,10 +539,15 @@ __device__ __forceinline__ void la_items(const Ctx<D, KN>& c, int j0, int jn, bo
 }
 
 template <int D, int KN, bool TEAM>
-__device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
+__device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c, const bool want_m) {
     Shared* sh = reinterpret_cast<Shared*>(lds_d);
     const int NB = c.NB, lane = c.lane, w = c.w;
     if (c.tid == 0) { sh->logdet = 0.0; sh->fail = 0; }
+    if (want_m) {
+        for (int idx = c.tid; idx < c.Npad; idx += NT) lds_d[c.L.alpha + idx] = 0.0;
+        if (TEAM && c.member == 0)
+            for (int idx = c.tid; idx < c.Npad; idx += NT) gst_d(c.ag + idx, 0.0);     // (drained by the first team barrier)
+    }
     __syncthreads();
     unsigned long long tA = 0, tB = 0, tC = 0, tW = 0, t0 = 0;
     for (int j0 = 0; j0 < NB; j0 += PR) {
@@ -430,7 +555,7 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
         if (TEAM) t0 = __builtin_amdgcn_s_memtime();
         // ---- (A) diagonal region: D_rr' = K_jr,jr' - sum_{k<j0} U_k,jr^T U_k,jr'  and  t_r = sum_{k<j0} U_k,jr^T z_k
         constexpr bool LA = !TEAM;                         // look-ahead of the next panel's diagonal region (la_items)
-        if (LA && c.tid == 0) { sh->gnext[0] = (j0 + PR < NB) ? 0 : 10; sh->g0done = 0; }
+        if (LA && c.tid == 0) { sh->gnext[0] = (j0 + PR < NB) ? 0 : 10; sh->g0done = 0; sh->gnext[1] = 0; }
         for (int bb = c.vw; bb < 10; bb += c.nwt) {
             int r, r2;
             diag_item(bb, r, r2);
@@ -551,7 +676,7 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
         // The 4-wave build (small tiles, at most ~9 column triples per panel for 4 waves) deals pairs: the finer items
         // balance better (fp64 fit of N = 500 tiles +3.4 %; single columns: the same).
         constexpr int PCW = TEAM ? 1 : (NW == 4 ? 2 : 3);
-        for (int i0 = j0 + nr + PCW * c.vw; i0 < NB; i0 += PCW * c.nwt) {
+        auto cols_item = [&](const int i0) {
             int ib[PCW];
 #pragma unroll
             for (int cc = 0; cc < PCW; ++cc) ib[cc] = (i0 + cc < NB) ? i0 + cc : -1;
@@ -622,6 +747,27 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
                     }
                 }
             }
+        };
+        if (TEAM) {
+            // static deal over the team's waves
+            for (int i0 = j0 + nr + PCW * c.vw; i0 < NB; i0 += PCW * c.nwt) cols_item(i0);
+            if (want_m) trtri_panel<D, KN, TEAM>(c, j0, nr);
+        } else {
+            // one workgroup: ONE queue over the panel's items -- the triangle of the inverse (the longest), the U columns,
+            // the column pairs of the inverse (longest first) -- so that the waves finish together whatever the mix; every
+            // item is the same arithmetic whoever runs it, and alpha has one writer per column and panel
+            const int nT = want_m ? 1 : 0;
+            const int nU = (NB - j0 - nr + PCW - 1) / PCW;
+            const int nM = want_m ? j0 / 2 : 0;
+            for (;;) {
+                int v = 0;
+                if (lane == 0) v = atomicAdd(&sh->gnext[1], 1);
+                const int idx = __builtin_amdgcn_readfirstlane(v);
+                if (idx >= nT + nU + nM) break;
+                if (idx < nT) trtri_triangle<D, KN, TEAM>(c, j0, nr);
+                else if (idx < nT + nU) cols_item(j0 + nr + PCW * (idx - nT));
+                else trtri_pair<D, KN, TEAM>(c, j0, nr, idx - nT - nU);
+            }
         }
         if (LA) la_items<D, KN>(c, j0, j0 + PR, false);
         team_barrier<TEAM>(c);
@@ -633,132 +779,14 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c) {
         __hip_atomic_fetch_add(&c.tc->pad1[2], (int)tB, RLX_AGENT);
         __hip_atomic_fetch_add(&c.tc->pad1[3], (int)tC, RLX_AGENT);
     }
+    if (TEAM && want_m && !sh->fail)
+        for (int idx = c.tid; idx < c.Npad; idx += NT) lds_d[c.L.alpha + idx] = gld_d(c.ag + idx);
     __syncthreads();
 }
 
 // ---- phase 2: M = L^-1 (lower slots), alpha = M^T z, by panels of PR block rows (same blocking as phase_potrf:
 // a wave owns pairs of block columns, 4 x 2 accumulators, every streamed block is loaded once per 4 products):
 //   M_ij = -L_i^-1 sum_{k=j}^{i-1} U_ki^T M_kj   (M_jj = L_j^-1 already in the diagonal slot)
-// Team: alpha lives in the owner's workspace (one writer per column and panel; panels separated by team barriers, so every
-// column's sum keeps the order it has in one workgroup) and comes into every member's LDS at the end.
-template <int D, int KN, bool TEAM>
-__device__ __forceinline__ void phase_trtri(Ctx<D, KN>& c) {
-    const int NB = c.NB, lane = c.lane;
-    for (int idx = c.tid; idx < c.Npad; idx += NT) lds_d[c.L.alpha + idx] = 0.0;
-    if (TEAM && c.member == 0)
-        for (int idx = c.tid; idx < c.Npad; idx += NT) gst_d(c.ag + idx, 0.0);
-    team_barrier<TEAM>(c);
-    for (int i0 = 0; i0 < NB; i0 += PR) {
-        const int nr = min(PR, NB - i0);
-        // (1) column pairs left of the panel
-        for (int p = c.vw; 2 * p < i0; p += c.nwt) {
-            const int jc0 = 2 * p, jc1 = jc0 + 1;
-            f64x4 acc[PR][2];
-#pragma unroll
-            for (int r = 0; r < PR; ++r) { acc[r][0] = zero4(); acc[r][1] = zero4(); }
-            {
-                f64x4 A[PR], B0, B1;
-#pragma unroll
-                for (int r = 0; r < PR; ++r) A[r] = ldg(c.ws, (r < nr) ? jc0 * NB + i0 + r : c.zb, lane);
-                B0 = ldg(c.ws, jc0 * NB + jc0, lane);
-                B1 = ldg(c.ws, c.zb, lane);                         // M_k,jc1 is zero for k = jc0 < jc1
-                for (int k = jc0; k + 1 < i0; ++k) {          // last step peeled: unconditional loads, no copy-first
-                    f64x4 nA[PR], nB0, nB1;
-#pragma unroll
-                    for (int r = 0; r < PR; ++r) nA[r] = ldg(c.ws, (r < nr) ? (k + 1) * NB + i0 + r : c.zb, lane);
-                    nB0 = ldg(c.ws, (k + 1) * NB + jc0, lane);
-                    nB1 = ldg(c.ws, (k + 1) * NB + jc1, lane);
-#pragma unroll
-                    for (int r = 0; r < PR; ++r) { mma_blk(acc[r][0], A[r], B0); mma_blk(acc[r][1], A[r], B1); }
-#pragma unroll
-                    for (int r = 0; r < PR; ++r) A[r] = nA[r];
-                    B0 = nB0; B1 = nB1;
-                }
-                if (jc0 < i0) {
-#pragma unroll
-                    for (int r = 0; r < PR; ++r) { mma_blk(acc[r][0], A[r], B0); mma_blk(acc[r][1], A[r], B1); }
-                }
-            }
-            double ap0 = 0.0, ap1 = 0.0;
-#pragma unroll
-            for (int r = 0; r < PR; ++r) {
-                if (r < nr) {
-                    const int ir = i0 + r;
-                    const f64x4 Lop = ldg(c.ws, c.dT0 + ir, lane);
-                    f64x4 X0 = zero4(), X1 = zero4();
-                    mma_blk(X0, Lop, acc[r][0]);
-                    mma_blk(X1, Lop, acc[r][1]);
-                    X0 = -X0; X1 = -X1;
-                    stg(c.ws, ir * NB + jc0, lane, X0);
-                    stg(c.ws, ir * NB + jc1, lane, X1);
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const double zr = lds_d[c.L.z + BS * ir + rowof(rr, c.q)];
-                        ap0 = fma(X0[rr], zr, ap0);
-                        ap1 = fma(X1[rr], zr, ap1);
-                    }
-#pragma unroll
-                    for (int r2 = r + 1; r2 < PR; ++r2) {
-                        if (r2 < nr) {
-                            const f64x4 U = ldg(c.ws, ir * NB + i0 + r2, lane);
-                            mma_blk(acc[r2][0], U, X0);
-                            mma_blk(acc[r2][1], U, X1);
-                        }
-                    }
-                }
-            }
-            ap0 = qsum(ap0); ap1 = qsum(ap1);
-            if (c.q == 0) {                              // a column pair always belongs to the same wave: no race
-                if (TEAM) {
-                    gdouble *a0 = c.ag + BS * jc0 + c.g, *a1 = c.ag + BS * jc1 + c.g;
-                    gst_d(a0, gld_d(a0) + ap0);
-                    gst_d(a1, gld_d(a1) + ap1);
-                } else {
-                    lds_d[c.L.alpha + BS * jc0 + c.g] += ap0;
-                    lds_d[c.L.alpha + BS * jc1 + c.g] += ap1;
-                }
-            }
-        }
-        // (2) the triangle inside the panel (one wave, the next in the round-robin of (1))
-        if (c.vw == ((i0 >> 1) % c.nwt)) {
-            for (int j = i0; j < i0 + nr; ++j) {
-                const f64x4 Mjj = ldg(c.ws, j * NB + j, lane);
-                double ap = 0.0;
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) ap = fma(Mjj[rr], lds_d[c.L.z + BS * j + rowof(rr, c.q)], ap);
-                for (int i = j + 1; i < i0 + nr; ++i) {
-                    f64x4 acc = zero4();
-                    for (int k = j; k < i; ++k) {
-                        const f64x4 A = ldg(c.ws, k * NB + i, lane);        // U_ki
-                        const f64x4 B = ldg(c.ws, k * NB + j, lane);        // M_kj (k == j: diagonal slot)
-                        mma_blk(acc, A, B);
-                    }
-                    const f64x4 Lop = ldg(c.ws, c.dT0 + i, lane);
-                    f64x4 Mij = zero4();
-                    mma_blk(Mij, Lop, acc);
-                    Mij = -Mij;
-                    stg(c.ws, i * NB + j, lane, Mij);
-                    // this wave reads the block back a few instructions later (k = i of the next row): a write-through store
-                    // still on its way is not ordered before a load of the same bytes
-                    if (TEAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) ap = fma(Mij[rr], lds_d[c.L.z + BS * i + rowof(rr, c.q)], ap);
-                }
-                const double a = qsum(ap);
-                if (c.q == 0) {
-                    if (TEAM) { gdouble* aj = c.ag + BS * j + c.g; gst_d(aj, gld_d(aj) + a); }
-                    else lds_d[c.L.alpha + BS * j + c.g] += a;
-                }
-            }
-        }
-        team_barrier<TEAM>(c);
-    }
-    if (TEAM) {
-        for (int idx = c.tid; idx < c.Npad; idx += NT) lds_d[c.L.alpha + idx] = gld_d(c.ag + idx);
-        __syncthreads();
-    }
-}
-
 // ---- phase 3: K^-1 blocks (K^-1)_ab = sum_{c>=a} M_ca^T M_cb, a >= b, contracted with dK/dtheta: 4 block rows a x
 // 2 block columns b per wave and step (the same 4 x 2 blocking; operands that would fall above the diagonal are the
 // zero block)
@@ -770,11 +798,27 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
     Shared* sh = reinterpret_cast<Shared*>(lds_d);
     const int NB = c.NB, lane = c.lane;
     double* gpart = reinterpret_cast<double*>(reinterpret_cast<char*>(c.ws) + c.gp0);
+    // one workgroup: the items (longest first: their k-loops run from a0 to NB) are pulled from a queue; a team deals them
+    int mine = TEAM ? c.vw : -1;
+    if (!TEAM) {
+        if (c.tid == 0) sh->gradnext = 0;
+        __syncthreads();
+        int v = 0;
+        if (lane == 0) v = atomicAdd(&sh->gradnext, 1);
+        mine = __builtin_amdgcn_readfirstlane(v);
+    }
     int item = 0;
     for (int a0 = 0; a0 < NB; a0 += PR) {
         const int na = min(PR, NB - a0);
         for (int b0 = 0; b0 < a0 + na; b0 += 2, ++item) {
-            if ((item % c.nwt) != c.vw) continue;
+            if (item != mine) continue;
+            if (TEAM) {
+                mine += c.nwt;
+            } else {
+                int v = 0;
+                if (lane == 0) v = atomicAdd(&sh->gradnext, 1);
+                mine = __builtin_amdgcn_readfirstlane(v);
+            }
             const bool hb1 = b0 + 1 < NB;
             f64x4 acc[PR][2];
 #pragma unroll
@@ -876,7 +920,7 @@ __device__ __forceinline__ void evaluate(Ctx<D, KN>& c, bool want_grad, const do
         for (int d = 0; d < D; ++d) lds_d[c.L.xsc + d * c.Npad + idx] = (idx < c.N) ? Xg[(size_t)idx * D + d] / sh->theta[d] : 0.0;
     }
     __syncthreads();
-    phase_potrf<D, KN, TEAM>(c);
+    phase_potrf<D, KN, TEAM>(c, want_grad);
     if (sh->fail) {
         if (c.tid == 0) { sh->nll = __builtin_inf(); for (int i = 0; i < D + 2; ++i) sh->gth[i] = 0.0; }
         __syncthreads();
@@ -894,10 +938,7 @@ __device__ __forceinline__ void evaluate(Ctx<D, KN>& c, bool want_grad, const do
         sh->nll = 0.5 * s + sh->logdet + 0.5 * (double)c.N * 1.8378770664093453;
     }
     __syncthreads();
-    if (want_grad) {
-        phase_trtri<D, KN, TEAM>(c);
-        phase_grad<D, KN, TEAM>(c);
-    }
+    if (want_grad) phase_grad<D, KN, TEAM>(c);
     if (c.tid == 0) {
         sh->n_eval += 1;
         if (!(sh->nll == sh->nll)) sh->fail = 1;
