@@ -47,6 +47,21 @@ extern __shared__ __attribute__((aligned(16))) double lds_d[];
 constexpr int BS = 16;         // block size
 constexpr int BLK = 256;       // doubles per block
 
+// Diagnostic build only (-DGPSAT_PROFILE, scripts/phase_profile_f64.py): per-wave cycle counters per code segment in LDS,
+// flushed to KernelArgs::prof.  No stamp executes in the product build.
+#ifdef GPSAT_PROFILE
+#define PROF_BEGIN() unsigned long long prof_t_ = __builtin_amdgcn_s_memtime()
+#define PROF_END(c_, slot_)                                                                              \
+    do {                                                                                                 \
+        unsigned long long t1_ = __builtin_amdgcn_s_memtime();                                           \
+        if ((c_).lane == 0) reinterpret_cast<Shared*>(lds_d)->prof[(c_).w * 16 + (slot_)] += t1_ - prof_t_; \
+        prof_t_ = t1_;                                                                                   \
+    } while (0)
+#else
+#define PROF_BEGIN() do {} while (0)
+#define PROF_END(c_, slot_) do {} while (0)
+#endif
+
 __device__ __forceinline__ int rowof(int r, int q) { return q + 4 * r; }
 
 // Workspace blocks.  A tile run by ONE workgroup moves them with plain global loads / stores (the CU's own L1 / L2 serve
@@ -289,15 +304,36 @@ __device__ __forceinline__ void contract(const Ctx<D, KN>& c, const f64x4& kinv,
     }
 }
 
-__device__ __forceinline__ double readlane_d(double v, int l) {
-    const unsigned long long u = __double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xffffffffull), l);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), l);
-    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+// 16x16 diagonal block: W = L L^T, X = L^-1 by Gaussian elimination of [W | I] (lane i (and its mirrors in the other three
+// 16-lane rows) owns row i), X = D^-1/2 L1^-1.  Out: S1 = X, S2 = X^T (acc layout), logsum, bad.
+// The pivot row reaches the other rows as a DPP row broadcast (v_mov_b64_dpp row_newbcast:k -- lane k of every 16-lane row,
+// the one 64-bit DPP control gfx950 has) straight into a VGPR: v_readlane pairs through one SGPR pair cost four
+// instructions and a wait state per multiply-add (12.6 k cycles per block, the serial part (B) of phase_potrf 25 % of an
+// evaluation of an N = 500 tile).  Same arithmetic in the same order: bit-identical results.
+template <int K>
+__device__ __forceinline__ double row_bcast(double v) { return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, true); }
+
+template <int K>
+__device__ __forceinline__ void diag_step(double (&a)[16], double (&e)[16], int g, double& mypiv, int& isbad) {
+    double p = row_bcast<K>(a[K]);
+    if (!(p > 0.0)) { isbad = 1; p = 1.0; }
+    mypiv = (g == K) ? p : mypiv;
+    // m = a[K] / p without v_div_scale / v_div_fmas / v_div_fixup (pivots are positive and far from the exponent range's
+    // ends): v_rcp_f64 (24 bits) + one Newton step (48 bits), the quotient corrected by its residual -- 6 dependent
+    // instructions instead of 12.  The chain shares its SIMD with an MFMA-dense wave of the CU's other workgroup, which
+    // issues a 64-cycle MFMA into every dependence gap: depth, not count, is what this code costs.
+    const double x0 = __builtin_amdgcn_rcp(p);
+    const double x1 = fma(x0, fma(-p, x0, 1.0), x0);
+    const double qq = a[K] * x1;
+    double m = fma(fma(-p, qq, a[K]), x1, qq);
+    m = (g > K) ? m : 0.0;
+#pragma unroll
+    for (int cc = K + 1; cc < 16; ++cc) a[cc] = fma(-m, row_bcast<K>(a[cc]), a[cc]);
+#pragma unroll
+    for (int cc = 0; cc <= K; ++cc) e[cc] = fma(-m, row_bcast<K>(e[cc]), e[cc]);
+    if constexpr (K + 1 < 16) diag_step<K + 1>(a, e, g, mypiv, isbad);
 }
 
-// 16x16 diagonal block: W = L L^T, X = L^-1 by Gaussian elimination of [W | I] (lane i (and its mirrors) owns row i,
-// pivot row broadcast by cross-lane reads), X = D^-1/2 L1^-1.  Out: S1 = X, S2 = X^T (acc layout), logsum, bad.
 __device__ __forceinline__ void diag_factor(const f64x4& W, int Ad, int lane, f64x4& S1, f64x4& S2, double& logsum, int& bad) {
     const int q = lane >> 4, g = lane & 15;
 #pragma unroll
@@ -308,18 +344,7 @@ __device__ __forceinline__ void diag_factor(const f64x4& W, int Ad, int lane, f6
     for (int cc = 0; cc < 16; ++cc) { a[cc] = lds_d[Ad + g * 17 + cc]; e[cc] = (cc == g) ? 1.0 : 0.0; }
     int isbad = 0;
     double mypiv = 1.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        double p = readlane_d(a[k], k);
-        if (!(p > 0.0)) { isbad = 1; p = 1.0; }
-        mypiv = (g == k) ? p : mypiv;
-        double m = a[k] / p;
-        m = (g > k) ? m : 0.0;
-#pragma unroll
-        for (int cc = k + 1; cc < 16; ++cc) a[cc] = fma(-m, readlane_d(a[cc], k), a[cc]);
-#pragma unroll
-        for (int cc = 0; cc <= k; ++cc) e[cc] = fma(-m, readlane_d(e[cc], k), e[cc]);
-    }
+    diag_step<0>(a, e, g, mypiv, isbad);
     const double rs = 1.0 / sqrt(mypiv);
     wave_lds_sync();
     if (q == 0) {
@@ -538,6 +563,84 @@ __device__ __forceinline__ void la_items(const Ctx<D, KN>& c, int j0, int jn, bo
     }
 }
 
+// One item of the column phase (C): PCW block columns right of the panel j0 .. j0 + nr, k-loop over the rows above the panel,
+// then the in-panel triangular solve with the panel's factors from LDS (pnb: the panel's ten blocks, slot (r,r) = (L_r^-1)^T,
+// slot (r,r') = U_jr,jr').
+template <int D, int KN, bool TEAM, int PCW>
+__device__ __forceinline__ void cols_item(const Ctx<D, KN>& c, const int j0, const int nr, const int i0, const int pnb) {
+    const int NB = c.NB, lane = c.lane;
+    int ib[PCW];
+#pragma unroll
+    for (int cc = 0; cc < PCW; ++cc) ib[cc] = (i0 + cc < NB) ? i0 + cc : -1;
+    f64x4 acc[PR][PCW];
+#pragma unroll
+    for (int r = 0; r < PR; ++r)
+#pragma unroll
+        for (int cc = 0; cc < PCW; ++cc) acc[r][cc] = zero4();
+    if (j0 > 0) {
+        f64x4 A[PR], B[PCW];
+#pragma unroll
+        for (int r = 0; r < PR; ++r) A[r] = ldg(c.ws, (r < nr) ? j0 + r : c.zb, lane);
+#pragma unroll
+        for (int cc = 0; cc < PCW; ++cc) B[cc] = ldg(c.ws, ib[cc] >= 0 ? ib[cc] : c.zb, lane);
+        // last step peeled: the loads of the next operands are unconditional (a conditional load makes the compiler
+        // copy the whole operand set first)
+        for (int k = 0; k + 1 < j0; ++k) {
+            f64x4 nA[PR], nB[PCW];
+#pragma unroll
+            for (int r = 0; r < PR; ++r) nA[r] = ldg(c.ws, (r < nr) ? (k + 1) * NB + j0 + r : c.zb, lane);
+#pragma unroll
+            for (int cc = 0; cc < PCW; ++cc) nB[cc] = ldg(c.ws, ib[cc] >= 0 ? (k + 1) * NB + ib[cc] : c.zb, lane);
+#pragma unroll
+            for (int r = 0; r < PR; ++r)
+#pragma unroll
+                for (int cc = 0; cc < PCW; ++cc) mma_blk(acc[r][cc], A[r], B[cc]);
+#pragma unroll
+            for (int r = 0; r < PR; ++r) A[r] = nA[r];
+#pragma unroll
+            for (int cc = 0; cc < PCW; ++cc) B[cc] = nB[cc];
+        }
+#pragma unroll
+        for (int r = 0; r < PR; ++r)
+#pragma unroll
+            for (int cc = 0; cc < PCW; ++cc) mma_blk(acc[r][cc], A[r], B[cc]);
+    }
+    // right-hand sides, then the in-panel triangular solve: X_r = L_r^-1 (W_r - sum_{r''<r} U_r''r^T X_r'')
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+        if (r < nr) {
+#pragma unroll
+            for (int cc = 0; cc < PCW; ++cc)
+                if (ib[cc] >= 0) acc[r][cc] = kblock<D, KN>(c, j0 + r, ib[cc]) - acc[r][cc];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+        if (r < nr) {
+            const f64x4 Lop = ldl(pnb + pidx(r, r) * BLK, lane);
+            f64x4 X[PCW];
+#pragma unroll
+            for (int cc = 0; cc < PCW; ++cc) {
+                X[cc] = zero4();
+                mma_blk(X[cc], Lop, acc[r][cc]);
+                if (ib[cc] >= 0) stg(c.ws, (j0 + r) * NB + ib[cc], lane, X[cc]);
+            }
+#pragma unroll
+            for (int r2 = r + 1; r2 < PR; ++r2) {
+                if (r2 < nr) {
+                    const f64x4 U = ldl(pnb + pidx(r, r2) * BLK, lane);
+#pragma unroll
+                    for (int cc = 0; cc < PCW; ++cc) {
+                        f64x4 T = zero4();
+                        mma_blk(T, U, X[cc]);
+                        acc[r2][cc] -= T;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int D, int KN, bool TEAM>
 __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c, const bool want_m) {
     Shared* sh = reinterpret_cast<Shared*>(lds_d);
@@ -550,6 +653,7 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c, const bool want_m) {
     }
     __syncthreads();
     unsigned long long tA = 0, tB = 0, tC = 0, tW = 0, t0 = 0;
+    PROF_BEGIN();
     for (int j0 = 0; j0 < NB; j0 += PR) {
         const int nr = min(PR, NB - j0);
         if (TEAM) t0 = __builtin_amdgcn_s_memtime();
@@ -588,12 +692,29 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c, const bool want_m) {
             }
         }
         if (TEAM) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tW += t1 - t0; t0 = t1; }
+        PROF_END(c, 0);
         team_barrier<TEAM>(c);
+        PROF_END(c, 1);
         if (TEAM) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tA += t1 - t0; t0 = t1; }
         // ---- (B) the 4 x 4 block triangle (wave 0 of the owner): after it slot (r,r) of Pn holds (L_r^-1)^T, slot (r,r')
         // holds U_jr,jr'
-        if (LA && w != 0) la_items<D, KN>(c, j0, j0 + PR, true);
+        constexpr int PCW = TEAM ? 1 : (NW == 4 ? 2 : 3);
+        // one workgroup: ONE queue over the panel's items of the column phase (C) -- the triangle of the inverse (the longest),
+        // the U columns, the column pairs of the inverse (longest first)
+        const int nT = want_m ? 1 : 0;
+        const int nU = (NB - j0 - nr + PCW - 1) / PCW;
+        const int nM = want_m ? j0 / 2 : 0;
+        auto queue_item = [&](const int idx) {
+            if (idx < nT) { trtri_triangle<D, KN, TEAM>(c, j0, nr); PROF_END(c, 6); }
+            else if (idx < nT + nU) { cols_item<D, KN, TEAM, PCW>(c, j0, nr, j0 + nr + PCW * (idx - nT), c.L.Pn); PROF_END(c, 5); }
+            else { trtri_pair<D, KN, TEAM>(c, j0, nr, idx - nT - nU); PROF_END(c, 7); }
+        };
+        if (LA && w != 0) { la_items<D, KN>(c, j0, j0 + PR, true); PROF_END(c, 3); }
         if (w == 0 && c.member == 0) {
+            // the serial part: this wave's VALU chain shares its SIMD with a wave of the CU's other workgroup, whose MFMAs
+            // (64 cycles each, nothing else issues meanwhile) slip into every dependence gap -- measured 23 cycles per
+            // instruction; with priority the arbiter takes this wave's instruction whenever one is ready
+            __builtin_amdgcn_s_setprio(3);
             f64x4 Dd[10];
 #pragma unroll
             for (int bb = 0; bb < 10; ++bb) Dd[bb] = TEAM ? ldg(c.ws, c.pn0 + bb, lane) : ldl(c.L.Pn + bb * BLK, lane);
@@ -605,7 +726,9 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c, const bool want_m) {
                     f64x4 S1, S2;
                     double ls;
                     int bad;
+                    PROF_END(c, 2);
                     diag_factor(Dd[pidx(r, r)], c.L.Ad, lane, S1, S2, ls, bad);
+                    PROF_END(c, 15);
                     stg(c.ws, jr * NB + jr, lane, S1);
                     stg(c.ws, c.dT0 + jr, lane, S2);
                     stl(c.L.Pn + pidx(r, r) * BLK, lane, S2);
@@ -653,8 +776,11 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c, const bool want_m) {
                 }
             }
             if (LA && lane == 0) __hip_atomic_store(&sh->g0done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_s_setprio(0);
+            PROF_END(c, 2);
         }
         team_barrier<TEAM>(c);
+        PROF_END(c, 4);
         if (TEAM) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tB += t1 - t0; t0 = t1; }
         if (TEAM) {
             // the owner's results of (B) for the other members: the panel's factors and U blocks into LDS, its rows of z, and
@@ -675,102 +801,25 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c, const bool want_m) {
         // are what more workgroups can use.
         // The 4-wave build (small tiles, at most ~9 column triples per panel for 4 waves) deals pairs: the finer items
         // balance better (fp64 fit of N = 500 tiles +3.4 %; single columns: the same).
-        constexpr int PCW = TEAM ? 1 : (NW == 4 ? 2 : 3);
-        auto cols_item = [&](const int i0) {
-            int ib[PCW];
-#pragma unroll
-            for (int cc = 0; cc < PCW; ++cc) ib[cc] = (i0 + cc < NB) ? i0 + cc : -1;
-            f64x4 acc[PR][PCW];
-#pragma unroll
-            for (int r = 0; r < PR; ++r)
-#pragma unroll
-                for (int cc = 0; cc < PCW; ++cc) acc[r][cc] = zero4();
-            if (j0 > 0) {
-                f64x4 A[PR], B[PCW];
-#pragma unroll
-                for (int r = 0; r < PR; ++r) A[r] = ldg(c.ws, (r < nr) ? j0 + r : c.zb, lane);
-#pragma unroll
-                for (int cc = 0; cc < PCW; ++cc) B[cc] = ldg(c.ws, ib[cc] >= 0 ? ib[cc] : c.zb, lane);
-                // last step peeled: the loads of the next operands are unconditional (a conditional load makes the compiler
-                // copy the whole operand set first)
-                for (int k = 0; k + 1 < j0; ++k) {
-                    f64x4 nA[PR], nB[PCW];
-#pragma unroll
-                    for (int r = 0; r < PR; ++r) nA[r] = ldg(c.ws, (r < nr) ? (k + 1) * NB + j0 + r : c.zb, lane);
-#pragma unroll
-                    for (int cc = 0; cc < PCW; ++cc) nB[cc] = ldg(c.ws, ib[cc] >= 0 ? (k + 1) * NB + ib[cc] : c.zb, lane);
-#pragma unroll
-                    for (int r = 0; r < PR; ++r)
-#pragma unroll
-                        for (int cc = 0; cc < PCW; ++cc) mma_blk(acc[r][cc], A[r], B[cc]);
-#pragma unroll
-                    for (int r = 0; r < PR; ++r) A[r] = nA[r];
-#pragma unroll
-                    for (int cc = 0; cc < PCW; ++cc) B[cc] = nB[cc];
-                }
-#pragma unroll
-                for (int r = 0; r < PR; ++r)
-#pragma unroll
-                    for (int cc = 0; cc < PCW; ++cc) mma_blk(acc[r][cc], A[r], B[cc]);
-            }
-            // right-hand sides, then the in-panel triangular solve: X_r = L_r^-1 (W_r - sum_{r''<r} U_r''r^T X_r'')
-#pragma unroll
-            for (int r = 0; r < PR; ++r) {
-                if (r < nr) {
-#pragma unroll
-                    for (int cc = 0; cc < PCW; ++cc)
-                        if (ib[cc] >= 0) acc[r][cc] = kblock<D, KN>(c, j0 + r, ib[cc]) - acc[r][cc];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < PR; ++r) {
-                if (r < nr) {
-                    const f64x4 Lop = ldl(c.L.Pn + pidx(r, r) * BLK, lane);
-                    f64x4 X[PCW];
-#pragma unroll
-                    for (int cc = 0; cc < PCW; ++cc) {
-                        X[cc] = zero4();
-                        mma_blk(X[cc], Lop, acc[r][cc]);
-                        if (ib[cc] >= 0) stg(c.ws, (j0 + r) * NB + ib[cc], lane, X[cc]);
-                    }
-#pragma unroll
-                    for (int r2 = r + 1; r2 < PR; ++r2) {
-                        if (r2 < nr) {
-                            const f64x4 U = ldl(c.L.Pn + pidx(r, r2) * BLK, lane);
-#pragma unroll
-                            for (int cc = 0; cc < PCW; ++cc) {
-                                f64x4 T = zero4();
-                                mma_blk(T, U, X[cc]);
-                                acc[r2][cc] -= T;
-                            }
-                        }
-                    }
-                }
-            }
-        };
         if (TEAM) {
             // static deal over the team's waves
-            for (int i0 = j0 + nr + PCW * c.vw; i0 < NB; i0 += PCW * c.nwt) cols_item(i0);
+            for (int i0 = j0 + nr + PCW * c.vw; i0 < NB; i0 += PCW * c.nwt) cols_item<D, KN, TEAM, PCW>(c, j0, nr, i0, c.L.Pn);
             if (want_m) trtri_panel<D, KN, TEAM>(c, j0, nr);
         } else {
-            // one workgroup: ONE queue over the panel's items -- the triangle of the inverse (the longest), the U columns,
-            // the column pairs of the inverse (longest first) -- so that the waves finish together whatever the mix; every
-            // item is the same arithmetic whoever runs it, and alpha has one writer per column and panel
-            const int nT = want_m ? 1 : 0;
-            const int nU = (NB - j0 - nr + PCW - 1) / PCW;
-            const int nM = want_m ? j0 / 2 : 0;
+            // the waves finish together whatever the mix; every item is the same arithmetic whoever runs it, and alpha has one
+            // writer per column and panel
             for (;;) {
                 int v = 0;
                 if (lane == 0) v = atomicAdd(&sh->gnext[1], 1);
                 const int idx = __builtin_amdgcn_readfirstlane(v);
                 if (idx >= nT + nU + nM) break;
-                if (idx < nT) trtri_triangle<D, KN, TEAM>(c, j0, nr);
-                else if (idx < nT + nU) cols_item(j0 + nr + PCW * (idx - nT));
-                else trtri_pair<D, KN, TEAM>(c, j0, nr, idx - nT - nU);
+                queue_item(idx);
             }
         }
         if (LA) la_items<D, KN>(c, j0, j0 + PR, false);
+        PROF_END(c, 8);
         team_barrier<TEAM>(c);
+        PROF_END(c, 9);
         if (TEAM) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tC += t1 - t0; t0 = t1; }
     }
     if (TEAM && c.tid == 0 && c.member == 0) {       // developer: 100 MHz ticks of the owner's thread 0 per part (GPSAT_DEBUG_TEAM_STATS)
@@ -800,6 +849,7 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
     double* gpart = reinterpret_cast<double*>(reinterpret_cast<char*>(c.ws) + c.gp0);
     // one workgroup: the items (longest first: their k-loops run from a0 to NB) are pulled from a queue; a team deals them
     int mine = TEAM ? c.vw : -1;
+    PROF_BEGIN();
     if (!TEAM) {
         if (c.tid == 0) sh->gradnext = 0;
         __syncthreads();
@@ -848,6 +898,7 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
                     for (int r = 0; r < PR; ++r) { mma_blk(acc[r][0], A[r], B0); mma_blk(acc[r][1], A[r], B1); }
                 }
             }
+            PROF_END(c, 10);
             double accl[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) accl[d] = 0.0;
@@ -874,10 +925,13 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
                 gp[D * 64] = accsf;
                 gp[(D + 1) * 64] = accsn;
             }
+            PROF_END(c, 13);
         }
     }
     const int nitems = item;
+    PROF_END(c, 10);
     team_barrier<TEAM>(c);
+    PROF_END(c, 11);
     if (c.member != 0) return;
     // fixed-order sum: wave w adds the items w, w + NW, ... per lane, then across lanes, then across waves
     double v[D + 2];
@@ -913,6 +967,7 @@ template <int D, int KN, bool TEAM>
 __device__ __forceinline__ void evaluate(Ctx<D, KN>& c, bool want_grad, const double* __restrict__ Xg) {
     Shared* sh = reinterpret_cast<Shared*>(lds_d);
     __syncthreads();
+    PROF_BEGIN();
     c.sf2 = sh->theta[D];
     c.sn2 = sh->theta[D + 1];
     for (int idx = c.tid; idx < c.Npad; idx += NT) {
@@ -944,6 +999,7 @@ __device__ __forceinline__ void evaluate(Ctx<D, KN>& c, bool want_grad, const do
         if (!(sh->nll == sh->nll)) sh->fail = 1;
     }
     __syncthreads();
+    PROF_END(c, 12);
 }
 
 template <int D, int KN, bool TEAM>
@@ -1092,6 +1148,9 @@ __global__ void __launch_bounds__(NT, F64_MIN_WG) gp_tile_kernel_f64(const Kerne
     c.g = c.lane & 15;
     const int NPmax = A.NBmax * BS;
     Shared* sh = reinterpret_cast<Shared*>(lds_d);
+#ifdef GPSAT_PROFILE
+    if (threadIdx.x < NW * 16) sh->prof[threadIdx.x] = 0ull;
+#endif
     int off = (int)((sizeof(Shared) + 15) / 16) * 2;
     c.L.xsc = off; off += D * NPmax;
     c.L.y = off; off += NPmax;
@@ -1261,6 +1320,10 @@ __global__ void __launch_bounds__(NT, F64_MIN_WG) gp_tile_kernel_f64(const Kerne
         }
         if (sliced && c.tid == 0) __hip_atomic_fetch_add(&A.ring_ctl[32], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#ifdef GPSAT_PROFILE
+    __syncthreads();
+    if (A.prof && c.tid < NW * 16) atomicAdd(&A.prof[c.tid], sh->prof[c.tid]);
+#endif
 }
 
 #ifndef GPSAT_F64_W4
