@@ -1788,7 +1788,13 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
             }
         } else if (c.tid == 0) {
             if (sliced) {
+#ifdef GPSAT_PROFILE
+                const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
                 sh->tile = ring_pop(A);
+#ifdef GPSAT_PROFILE
+                sh->prof[13] += __builtin_amdgcn_s_memtime() - tw0;      // time this workgroup waited for a tile (scripts/tail_profile.py)
+#endif
             } else {
                 const int slot = atomicAdd(A.queue, 1);
                 sh->tile = slot < A.T ? A.order[slot] : -1;

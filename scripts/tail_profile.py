@@ -35,3 +35,9 @@ print(f"{m.sum()} workgroups; kernel {r.kernel_ms:.2f} ms, {r.n_eval.mean():.2f}
 print(f"workgroups ran out of work at {end.min() / 1e3:.2f} .. {end.max() / 1e3:.2f} ms (mean {end.mean() / 1e3:.2f}); "
       f"idle at the end: {100 * (1 - end.mean() / end.max()):.1f} % of the launch")
 print("percentiles of the exit time / last exit:", np.round(np.percentile(end, [1, 10, 25, 50, 75, 90]) / end.max(), 3))
+pb = (C.c_ulonglong * 64)()
+lib.gpsat_debug_profile(eng._h, pb)
+pv = np.array(pb[:], dtype=np.float64).reshape(4, 16)
+if pv[0, 14] > 0:
+    print(f"time-sliced queue: the workgroups waited for a tile {100 * pv[0, 13] / (m.sum() * pv[0, 14]):.1f} % of the launch "
+          f"(sum of the waits / workgroups x launch, s_memtime ticks)")
