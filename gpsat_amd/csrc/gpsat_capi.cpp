@@ -94,7 +94,7 @@ int gpsat_device_count(void) {
 int gpsat_max_tile_obs(int dtype, int D) {
     // the largest tile whose workgroup state (coordinates, y, z, alpha, factor buffers, optimiser state) fits the
     // 160 KiB LDS of a CU with one workgroup per CU (8-wave builds)
-    if (D < 1 || D > 3 || (dtype != GPSAT_F32 && dtype != GPSAT_F64)) return 0;
+    if (D < 1 || D > 4 || (dtype != GPSAT_F32 && dtype != GPSAT_F64)) return 0;
     const bool f64 = dtype == GPSAT_F64;
     const int bs = f64 ? 16 : 32;
     for (int NB = 4096 / bs; NB >= 1; --NB) {
@@ -160,7 +160,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     if (!h || !b) return fail(GPSAT_EINVAL, "gpsat_fit_predict_batch: NULL handle or batch");
     if (b->T < 0) return fail(GPSAT_EINVAL, "T < 0");
     if (b->T == 0) return GPSAT_OK;
-    if (b->D < 1 || b->D > 3) return fail(GPSAT_EINVAL, "D must be 1..3 in this build");
+    if (b->D < 1 || b->D > 4) return fail(GPSAT_EINVAL, "D must be 1..4 in this build");
     if (b->dtype != GPSAT_F32 && b->dtype != GPSAT_F64) return fail(GPSAT_EINVAL, "unknown dtype");
     const bool f64 = b->dtype == GPSAT_F64;
     const size_t esz = f64 ? sizeof(double) : sizeof(float);

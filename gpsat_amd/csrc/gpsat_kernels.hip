@@ -2062,6 +2062,7 @@ hipError_t launch_tiles(int D, const KernelArgs& a, int grid, size_t smem, hipSt
         case 1: return launch_d<1>(a, grid, smem, stream);
         case 2: return launch_d<2>(a, grid, smem, stream);
         case 3: return launch_d<3>(a, grid, smem, stream);
+        case 4: return launch_d<4>(a, grid, smem, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -1576,6 +1576,7 @@ hipError_t F64FN(launch_tiles_f64)(int D, const KernelArgs& a, int grid, size_t 
         case 1: return F64NS::launch_d<1>(a, grid, smem, stream);
         case 2: return F64NS::launch_d<2>(a, grid, smem, stream);
         case 3: return F64NS::launch_d<3>(a, grid, smem, stream);
+        case 4: return F64NS::launch_d<4>(a, grid, smem, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -129,8 +129,8 @@ class HipGPRModel:
             raise ValueError("dtype must be 'f32' or 'f64'")
         self.dtype = dtype                                # device compute precision (the reference computes in fp64)
         D = self.coords.shape[1]
-        if D > 3:
-            raise NotImplementedError("HIP backend is built for 1..3 input dimensions")
+        if D > 4:
+            raise NotImplementedError("HIP backend is built for 1..4 input dimensions")
         self.D = D
         kk = dict(kernel_kwargs or {})
         ls = np.broadcast_to(np.asarray(kk.get("lengthscales", np.ones(D)), dtype=np.float64), (D,)).copy()

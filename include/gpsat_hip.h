@@ -99,7 +99,7 @@ typedef struct gpsat_opts {
 typedef struct gpsat_batch {
     /* ---- shape ---- */
     int32_t T;                 /* number of tiles                                           */
-    int32_t D;                 /* input dimension (1..3 in this build)                      */
+    int32_t D;                 /* input dimension (1..4 in this build)                      */
     int32_t dtype;             /* GPSAT_F32 (fp32 MFMA kernels) | GPSAT_F64 (fp64 MFMA kernels) */
     int32_t kernel;            /* GPSAT_KERNEL_*                                            */
     int32_t memory;            /* GPSAT_MEM_HOST / GPSAT_MEM_DEVICE for the bulk arrays      */

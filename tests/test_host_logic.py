@@ -89,6 +89,9 @@ def test_accessors_and_errors():
     with pytest.raises(NotImplementedError):
         HipGPRModel(coords=X, obs=yv, engine=_NoDevice(), kernel="Cosine")
     with pytest.raises(NotImplementedError):
+        HipGPRModel(coords=np.zeros((4, 5)), obs=np.arange(4.0), engine=_NoDevice())        # built for 1..4 input dimensions
+    assert HipGPRModel(coords=np.random.default_rng(0).normal(size=(4, 4)), obs=np.arange(4.0), engine=_NoDevice()).D == 4
+    with pytest.raises(NotImplementedError):
         get_model("GPflowSVGPModel")                                        # GPSat/models/__init__.py:24
     assert get_model("GPflowGPRModel") is HipGPRModel
     m._fix_hyperparameters(["kernel_variance", "not_a_param"])
