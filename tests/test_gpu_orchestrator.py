@@ -204,3 +204,45 @@ def test_orchestrator_fp64_predict_only_with_loaded_parameters(eng, tmp_path):
         np.testing.assert_allclose(p["f*"].values, f, rtol=0, atol=1e-8)
         np.testing.assert_allclose(p["f*_var"].values, fv, rtol=0, atol=1e-9)
         np.testing.assert_allclose(p["f_bar"].values, d["z"].values.mean(), rtol=1e-15)
+
+
+def test_orchestrator_four_input_dimensions_fp64(eng, tmp_path):
+    """Four coordinate columns (x, y, t and a depth-like d) through the orchestrator in fp64: tile membership by the
+    reference's predicate, and at the parameters each tile's optimiser returned the objective and the predictions equal
+    the oracle's (the D = 4 kernels; the reference takes any number of coordinate columns, GPSat/models/base_model.py:134-189)."""
+    from gpsat_amd.local_experts import BatchedLocalExpertOI
+    rng = np.random.default_rng(4)
+    M = 6000
+    df = pd.DataFrame({"x": rng.uniform(0, 1, M), "y": rng.uniform(0, 1, M), "t": rng.uniform(0, 6, M), "d": rng.uniform(0, 2, M)})
+    df["z"] = (np.sin(6 * df["x"]) * np.cos(5 * df["y"]) + 0.3 * np.sin(df["t"]) + 0.2 * df["d"] ** 2 + 0.05 * rng.normal(size=M))
+    xl = pd.DataFrame({"x": [0.3, 0.7, 0.5], "y": [0.4, 0.6, 0.5], "t": [3.0, 2.0, 4.0], "d": [1.0, 0.5, 1.5]})
+    cc = ["x", "y", "t", "d"]
+    oi = BatchedLocalExpertOI(
+        expert_loc_config={"source": xl},
+        data_config={"data_source": df, "obs_col": "z", "coords_col": cc,
+                     "local_select": [{"col": ["x", "y"], "comp": "<=", "val": 0.2}, {"col": "t", "comp": "<=", "val": 2.0},
+                                      {"col": "t", "comp": ">=", "val": -2.0}]},
+        model_config={"oi_model": "HipGPRModel", "init_params": {"kernel": "Matern32", "obs_mean": "local"},
+                      "constraints": {"lengthscales": {"low": [1e-3] * 4, "high": [5.0] * 4}}},
+        pred_loc_config={"method": "expert_loc"}, engine=eng, dtype="f64")
+    tabs = oi.run(store_path=str(tmp_path / "s4"))
+    rd, pr = tabs["run_details"], tabs["preds"]
+    assert len(rd) == 3 and rd["optimise_success"].all()
+    ls = tabs["lengthscales"]
+    assert sorted(ls["_dim_0"].unique().tolist()) == [0, 1, 2, 3]
+    for i in range(3):
+        loc = xl.iloc[i]
+        m = ((df["x"] - loc["x"]) ** 2 + (df["y"] - loc["y"]) ** 2 <= 0.2 ** 2) & (np.abs(df["t"] - loc["t"]) <= 2.0)
+        d = df[m]
+        key = tuple(loc[cc])
+        assert rd.loc[[key]]["num_obs"].values[0] == len(d)
+        th = np.concatenate([ls.loc[[key]].sort_values("_dim_0")["lengthscales"].values,
+                             tabs["kernel_variance"].loc[[key]]["kernel_variance"].values,
+                             tabs["likelihood_variance"].loc[[key]]["likelihood_variance"].values])
+        Xo, yo = d[cc].values, d["z"].values - d["z"].values.mean()
+        nll, _ = go.nll_and_grad(2, Xo, yo, th, want_grad=False)
+        assert rd.loc[[key]]["objective_value"].values[0] == pytest.approx(nll, rel=1e-9, abs=1e-7)
+        p = pr.loc[[key]]
+        f, fv, _ = go.predict(2, Xo, yo, p[[f"pred_loc_{c}" for c in cc]].values, th)
+        np.testing.assert_allclose(p["f*"].values, f, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(p["f*_var"].values, fv, rtol=0, atol=1e-8)
