@@ -145,6 +145,59 @@ __device__ __forceinline__ void mma_blk(f32x16& acc, const f32x16& a, const f32x
     for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
 }
 
+// ---- an fp32 block product on the bf16 pipe, exactly (scripts/bench_split_bf16.hip) -- the K^-1 phase of the 8-WAVE build.
+// An fp32 value is the exact sum of three bf16 values (8 + 8 + 8 significand bits, by truncation); S_A^T S_B as the six plane
+// products a1 b1, a1 b2, a2 b1, a1 b3, a3 b1, a2 b2 on v_mfma_f32_32x32x16_bf16 (fp32 accumulation; what is dropped is below
+// 2^-24 of a product) has the error of the fp32 MFMA product (1.6e-7 against 2.0e-7 of max |result|) at less than half its
+// cycles.  Registers 8m .. 8m+7 of a block in the accumulator layout are the 8-per-lane operand of that MFMA (the same k-slots
+// in A and B); the planes are made in registers from the half block as it was loaded, once for the two products that use it.
+// 8-wave build ONLY (one workgroup per CU, the phase between workgroup barriers: no fp32 MFMA of anybody shares a SIMD with
+// these): in the 4-wave build the bf16 MFMAs of one workgroup flip last bits in the fp32 sweep of the workgroup that shares
+// its SIMDs -- results were no longer reproducible bit for bit.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct RawHalf { u32x4 q[2]; };                  // registers 8m .. 8m+7 of a block, as loaded
+struct HalfPl { u32x4 p[3]; };                   // their three bf16 planes: 8 bf16 per lane and plane
+
+__device__ __forceinline__ RawHalf ldg_half(const float* __restrict__ ws, int blk, int m, int lane) {
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws), 0, 0x7fffffff, 0x00020000);
+    const int so = blk * (BLK * 4) + m * 2048, vo = lane * 16;
+    RawHalf h;
+    h.q[0] = __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, GPSAT_LD_AUX);
+    h.q[1] = __builtin_amdgcn_raw_buffer_load_b128(r, vo + 1024, so, GPSAT_LD_AUX);
+    return h;
+}
+
+__device__ __forceinline__ HalfPl split_half(const RawHalf& v) {
+    HalfPl P;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned x0 = v.q[j >> 1][2 * (j & 1)], x1 = v.q[j >> 1][2 * (j & 1) + 1];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            P.p[p][j] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);                // the upper halves: bf16 by truncation
+            if (p < 2) {
+                x0 = __float_as_uint(__uint_as_float(x0) - __uint_as_float(x0 & 0xffff0000u));
+                x1 = __float_as_uint(__uint_as_float(x1) - __uint_as_float(x1 & 0xffff0000u));
+            }
+        }
+    }
+    return P;
+}
+
+__device__ __forceinline__ f32x16 mfma_bf(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// acc += (half of S_A)^T * (half of S_B) from planes (6 MFMAs), the smallest terms first
+__device__ __forceinline__ void mma_half(f32x16& acc, const HalfPl& A, const HalfPl& B) {
+    acc = mfma_bf(A.p[1], B.p[1], acc);
+    acc = mfma_bf(A.p[0], B.p[2], acc);
+    acc = mfma_bf(A.p[2], B.p[0], acc);
+    acc = mfma_bf(A.p[0], B.p[1], acc);
+    acc = mfma_bf(A.p[1], B.p[0], acc);
+    acc = mfma_bf(A.p[0], B.p[0], acc);
+}
+
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll
@@ -1229,6 +1282,75 @@ __device__ __forceinline__ float ld_part(const float* __restrict__ ws, int byte_
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, byte_off, GPSAT_LD_AUX));
 }
 
+// The k-loop of a K^-1 group on the bf16 pipe (8-wave build): half blocks (16 k-rows) per step, the halves of step h + 1 in
+// flight while the halves of step h are split into planes and multiplied (24 MFMAs; 18 on the diagonal, where B = A and the
+// upper product is not needed).  Two operand sets in ping-pong (m = 0 / m = 1 of a block row): no register copies.
+struct KinvOps { RawHalf A0, A1, B0, B1; };
+
+template <bool DIAG>
+__device__ __forceinline__ void kinv_load(KinvOps& S, const float* __restrict__ ws, int NB, int cc, int m, int a0, int b0, int lane) {
+    S.A0 = ldg_half(ws, cc * NB + a0, m, lane);
+    S.A1 = ldg_half(ws, cc * NB + a0 + 1, m, lane);
+    if (!DIAG) {
+        S.B0 = ldg_half(ws, cc * NB + b0, m, lane);
+        S.B1 = ldg_half(ws, cc * NB + b0 + 1, m, lane);
+    }
+}
+
+template <bool DIAG>
+__device__ __forceinline__ void kinv_comp(f32x16 (&acc)[4], const KinvOps& S) {
+    const HalfPl A0 = split_half(S.A0), A1 = split_half(S.A1);
+    if (DIAG) {
+#define GPSAT_PP(i, j)                              \
+        acc[0] = mfma_bf(A0.p[i], A0.p[j], acc[0]); \
+        acc[2] = mfma_bf(A1.p[i], A0.p[j], acc[2]); \
+        acc[3] = mfma_bf(A1.p[i], A1.p[j], acc[3]);
+        GPSAT_PP(1, 1) GPSAT_PP(0, 2) GPSAT_PP(2, 0) GPSAT_PP(0, 1) GPSAT_PP(1, 0) GPSAT_PP(0, 0)
+#undef GPSAT_PP
+    } else {
+        const HalfPl B0 = split_half(S.B0), B1 = split_half(S.B1);
+#define GPSAT_PP(i, j)                              \
+        acc[0] = mfma_bf(A0.p[i], B0.p[j], acc[0]); \
+        acc[1] = mfma_bf(A0.p[i], B1.p[j], acc[1]); \
+        acc[2] = mfma_bf(A1.p[i], B0.p[j], acc[2]); \
+        acc[3] = mfma_bf(A1.p[i], B1.p[j], acc[3]);
+        GPSAT_PP(1, 1) GPSAT_PP(0, 2) GPSAT_PP(2, 0) GPSAT_PP(0, 1) GPSAT_PP(1, 0) GPSAT_PP(0, 0)
+#undef GPSAT_PP
+    }
+}
+
+// acc[0..3] = the blocks (a0, b0), (a0, b0 + 1), (a0 + 1, b0), (a0 + 1, b0 + 1) of K^-1 = M^T M (what a missing block row or
+// column leaves in its accumulators is not used by the caller)
+template <bool DIAG>
+__device__ __forceinline__ void kinv_kloop(const float* __restrict__ ws, int NB, int a0, int b0, int lane, f32x16 (&acc)[4]) {
+    const int a1 = a0 + 1;
+    // block row a0: only the A0 products (M_a0,a1 = 0)
+    RawHalf fA[2], fB0[2], fB1[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        fA[m] = ldg_half(ws, a0 * NB + a0, m, lane);
+        if (!DIAG) { fB0[m] = ldg_half(ws, a0 * NB + b0, m, lane); fB1[m] = ldg_half(ws, a0 * NB + b0 + 1, m, lane); }
+    }
+    KinvOps S0, S1;
+    if (a1 < NB) kinv_load<DIAG>(S0, ws, NB, a1, 0, a0, b0, lane);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const HalfPl A = split_half(fA[m]);
+        if (DIAG) mma_half(acc[0], A, A);
+        else {
+            const HalfPl B0 = split_half(fB0[m]), B1 = split_half(fB1[m]);
+            mma_half(acc[0], A, B0);
+            mma_half(acc[1], A, B1);
+        }
+    }
+    for (int cc = a1; cc < NB; ++cc) {
+        kinv_load<DIAG>(S1, ws, NB, cc, 1, a0, b0, lane);
+        kinv_comp<DIAG>(acc, S0);
+        kinv_load<DIAG>(S0, ws, NB, min(cc + 1, NB - 1), 0, a0, b0, lane);     // past the end: the last row again, unused
+        kinv_comp<DIAG>(acc, S1);
+    }
+}
+
 // one K^-1 group (a0 = 2 ia, b0 = 2 ib): k-loop, contraction, per-lane partial sums -> gpart[g]
 template <int D, int KN>
 __device__ __forceinline__ void grad_group(const Ctx<D, KN>& c, int g, int ia, int ib) {
@@ -1245,6 +1367,10 @@ __device__ __forceinline__ void grad_group(const Ctx<D, KN>& c, int g, int ia, i
     f32x16 acc[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[n] = zero16();
+#ifdef GPSAT_W8
+    if (ia == ib) kinv_kloop<true>(c.ws, NB, a0, b0, lane, acc);
+    else kinv_kloop<false>(c.ws, NB, a0, b0, lane, acc);
+#else
     // M_cc,x lives at block cc*NB + x (cc >= x).  First step cc = a0: only row a0 exists (M_a0,a1 = 0)
     f32x16 A0 = ldg(c.ws, a0 * NB + a0, lane);
     f32x16 B0 = ldg(c.ws, a0 * NB + b0, lane);
@@ -1278,6 +1404,7 @@ __device__ __forceinline__ void grad_group(const Ctx<D, KN>& c, int g, int ia, i
         mma_blk(acc[0], A0, B0);
         if (use01) mma_blk(acc[1], A0, B1);
     }
+#endif
     PROF_END(c, 6);
     float accl[D];
 #pragma unroll
