@@ -151,9 +151,9 @@ __device__ __forceinline__ void mma_blk(f32x16& acc, const f32x16& a, const f32x
 // 2^-24 of a product) has the error of the fp32 MFMA product (1.6e-7 against 2.0e-7 of max |result|) at less than half its
 // cycles.  Registers 8m .. 8m+7 of a block in the accumulator layout are the 8-per-lane operand of that MFMA (the same k-slots
 // in A and B); the planes are made in registers from the half block as it was loaded, once for the two products that use it.
-// 8-wave build ONLY (one workgroup per CU, the phase between workgroup barriers: no fp32 MFMA of anybody shares a SIMD with
-// these): in the 4-wave build the bf16 MFMAs of one workgroup flip last bits in the fp32 sweep of the workgroup that shares
-// its SIMDs -- results were no longer reproducible bit for bit.
+// 8-wave build ONLY (one workgroup per CU, the phase between workgroup barriers: every wave of the CU is in this loop or in the
+// contraction behind it).  In the 4-wave build, beside a second workgroup in another phase, results were no longer reproducible
+// bit for bit (11-420 of 4096 tiles per launch; with the settle pad below still 1 tile in ~10 launches).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct RawHalf { u32x4 q[2]; };                  // registers 8m .. 8m+7 of a block, as loaded
 struct HalfPl { u32x4 p[3]; };                   // their three bf16 planes: 8 bf16 per lane and plane
@@ -187,6 +187,13 @@ __device__ __forceinline__ HalfPl split_half(const RawHalf& v) {
 __device__ __forceinline__ f32x16 mfma_bf(const u32x4& a, const u32x4& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+
+// Between the VALU instructions that write the planes and the first MFMA that reads them: 8 wait states.  Without them the
+// MFMA can read a plane register before the split has landed in it -- when the matrix pipe is idle and the MFMA issues at once;
+// behind a busy pipe it never shows (every block product as plane products, 4085 of 4096 tiles irreproducible
+// without this pad, 1 with it; the K^-1 loop below: 11-420 without, 0 with).  hipcc (ROCm 7.2) inserts none here.
+#define GPSAT_PLANES_SETTLE(...) asm volatile("s_nop 7" : __VA_ARGS__)
+#define GPSAT_PL(P) "+v"((P).p[0]), "+v"((P).p[1]), "+v"((P).p[2])
 
 // acc += (half of S_A)^T * (half of S_B) from planes (6 MFMAs), the smallest terms first
 __device__ __forceinline__ void mma_half(f32x16& acc, const HalfPl& A, const HalfPl& B) {
@@ -1282,7 +1289,7 @@ __device__ __forceinline__ float ld_part(const float* __restrict__ ws, int byte_
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, byte_off, GPSAT_LD_AUX));
 }
 
-// The k-loop of a K^-1 group on the bf16 pipe (8-wave build): half blocks (16 k-rows) per step, the halves of step h + 1 in
+// The k-loop of a K^-1 group on the bf16 pipe: half blocks (16 k-rows) per step, the halves of step h + 1 in
 // flight while the halves of step h are split into planes and multiplied (24 MFMAs; 18 on the diagonal, where B = A and the
 // upper product is not needed).  Two operand sets in ping-pong (m = 0 / m = 1 of a block row): no register copies.
 struct KinvOps { RawHalf A0, A1, B0, B1; };
@@ -1299,8 +1306,9 @@ __device__ __forceinline__ void kinv_load(KinvOps& S, const float* __restrict__ 
 
 template <bool DIAG>
 __device__ __forceinline__ void kinv_comp(f32x16 (&acc)[4], const KinvOps& S) {
-    const HalfPl A0 = split_half(S.A0), A1 = split_half(S.A1);
+    HalfPl A0 = split_half(S.A0), A1 = split_half(S.A1);
     if (DIAG) {
+        GPSAT_PLANES_SETTLE(GPSAT_PL(A0), GPSAT_PL(A1));
 #define GPSAT_PP(i, j)                              \
         acc[0] = mfma_bf(A0.p[i], A0.p[j], acc[0]); \
         acc[2] = mfma_bf(A1.p[i], A0.p[j], acc[2]); \
@@ -1308,7 +1316,8 @@ __device__ __forceinline__ void kinv_comp(f32x16 (&acc)[4], const KinvOps& S) {
         GPSAT_PP(1, 1) GPSAT_PP(0, 2) GPSAT_PP(2, 0) GPSAT_PP(0, 1) GPSAT_PP(1, 0) GPSAT_PP(0, 0)
 #undef GPSAT_PP
     } else {
-        const HalfPl B0 = split_half(S.B0), B1 = split_half(S.B1);
+        HalfPl B0 = split_half(S.B0), B1 = split_half(S.B1);
+        GPSAT_PLANES_SETTLE(GPSAT_PL(A0), GPSAT_PL(A1), GPSAT_PL(B0), GPSAT_PL(B1));
 #define GPSAT_PP(i, j)                              \
         acc[0] = mfma_bf(A0.p[i], B0.p[j], acc[0]); \
         acc[1] = mfma_bf(A0.p[i], B1.p[j], acc[1]); \
@@ -1335,10 +1344,11 @@ __device__ __forceinline__ void kinv_kloop(const float* __restrict__ ws, int NB,
     if (a1 < NB) kinv_load<DIAG>(S0, ws, NB, a1, 0, a0, b0, lane);
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        const HalfPl A = split_half(fA[m]);
-        if (DIAG) mma_half(acc[0], A, A);
+        HalfPl A = split_half(fA[m]);
+        if (DIAG) { GPSAT_PLANES_SETTLE(GPSAT_PL(A)); mma_half(acc[0], A, A); }
         else {
-            const HalfPl B0 = split_half(fB0[m]), B1 = split_half(fB1[m]);
+            HalfPl B0 = split_half(fB0[m]), B1 = split_half(fB1[m]);
+            GPSAT_PLANES_SETTLE(GPSAT_PL(A), GPSAT_PL(B0), GPSAT_PL(B1));
             mma_half(acc[0], A, B0);
             mma_half(acc[1], A, B1);
         }
@@ -1367,7 +1377,7 @@ __device__ __forceinline__ void grad_group(const Ctx<D, KN>& c, int g, int ia, i
     f32x16 acc[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[n] = zero16();
-#ifdef GPSAT_W8
+#if defined(GPSAT_W8) || defined(GPSAT_KINV_BF16_W4)      // (the macro: developer builds of DESIGN.md E48)
     if (ia == ib) kinv_kloop<true>(c.ws, NB, a0, b0, lane, acc);
     else kinv_kloop<false>(c.ws, NB, a0, b0, lane, acc);
 #else
