@@ -140,7 +140,13 @@ __device__ __forceinline__ void stl(int off, int lane, const f32x16& v) {
 }
 
 // acc += S_A^T * S_B   (16 x v_mfma_f32_32x32x2_f32)
-__device__ __forceinline__ void mma_blk(f32x16& acc, const f32x16& a, const f32x16& b) {
+__device__ __forceinline__ void mma_blk(f32x16& acc, const f32x16& a0, const f32x16& b0) {
+#ifdef GPSAT_PAD_FP32            // developer: wait states between whatever wrote the operands and the first MFMA
+    f32x16 a = a0, b = b0;
+    asm volatile("s_nop 7" : "+v"(acc), "+v"(a), "+v"(b));
+#else
+    const f32x16 &a = a0, &b = b0;
+#endif
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
 }
