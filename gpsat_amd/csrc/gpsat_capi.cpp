@@ -76,6 +76,8 @@ struct gpsat_handle {
     // device buffers (grown lazily, owned by the handle)
     DevBuf meta_i64, meta_f64, meta_misc, out_f64, out_i32, bulk_in, bulk_out, ws, prof, ring, state, coop;
     DevBuf sel_pts, sel_refs, sel_cnt, sel_idx, sel_box, sel_perm, sel_keys, sel_tmp, sel_ord;
+    float* dump_dev = nullptr;         // diagnostic build (-DGPSAT_DUMP): caller's device buffer for per-tile factor dumps
+    size_t dump_stride = 0;
     unsigned long long prof_host[64 + 8 * 1024 + 2048] = {0};     // counters + event trace + per-workgroup start / end (diagnostic build)
 };
 
@@ -396,6 +398,14 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     a.cov_off = want_cov ? d_i64 + 2 * (T + 1) : nullptr;
     a.f_cov = want_cov ? reinterpret_cast<float*>(dcov) : nullptr;
     a.PCmax = PCcov;
+    a.dump = nullptr; a.dump_stride = 0;
+#ifdef GPSAT_DUMP
+    if (h->dump_dev && !f64) {
+        const size_t need = ((size_t)NBmax * NBmax + NBmax) * 1024 + 2 * (size_t)NBmax * 32 + 16 + 8 * 1024;
+        if (h->dump_stride < need) return fail(GPSAT_EINVAL, "dump stride too small: need " + std::to_string(need) + " floats per tile");
+        a.dump = h->dump_dev; a.dump_stride = h->dump_stride;
+    }
+#endif
 #ifdef GPSAT_PROFILE
     if ((rc = h->prof.reserve(sizeof(h->prof_host)))) return rc;
     HIP_TRY(hipMemsetAsync(h->prof.p, 0, sizeof(h->prof_host), h->stream));
@@ -473,6 +483,15 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     h->last_total_ms = tm;
     return GPSAT_OK;
 }
+
+#ifdef GPSAT_DUMP
+// diagnostic build only: device buffer [T][stride_floats] that every fp32 batch call fills (KernelArgs::dump)
+int gpsat_debug_set_dump(gpsat_handle* h, void* dev, unsigned long long stride_floats) {
+    if (!h) return GPSAT_EINVAL;
+    h->dump_dev = static_cast<float*>(dev); h->dump_stride = (size_t)stride_floats;
+    return GPSAT_OK;
+}
+#endif
 
 int gpsat_select_batch(gpsat_handle* h, const gpsat_select_spec* sp, int64_t M, int32_t C, const double* points,
                        int32_t T, const double* refs, int64_t* off, int32_t* idx, int64_t capacity) {

@@ -55,6 +55,10 @@ struct KernelArgs {
     int coop_min_nb;              // smallest tile (block columns) worth helping
     int coop_hdiv;                // helpers wanted per tile: NB / coop_hdiv (1..7)
     int coop_force;               // developer / tests: every evaluation of a helpable tile runs the cooperative code path, helped or not
+    // diagnostic builds only (-DGPSAT_DUMP, scripts/e48_dump_compare.py): per tile the factor square, DinvT, z, alpha and the
+    // log-determinant of its LAST evaluation, [T][dump_stride] floats in device memory; nullptr in the product
+    float* dump;
+    size_t dump_stride;
 };
 
 size_t shared_bytes(int D, int NBmax);

@@ -140,26 +140,22 @@ __device__ __forceinline__ void stl(int off, int lane, const f32x16& v) {
 }
 
 // acc += S_A^T * S_B   (16 x v_mfma_f32_32x32x2_f32)
-__device__ __forceinline__ void mma_blk(f32x16& acc, const f32x16& a0, const f32x16& b0) {
-#ifdef GPSAT_PAD_FP32            // developer: wait states between whatever wrote the operands and the first MFMA
-    f32x16 a = a0, b = b0;
-    asm volatile("s_nop 7" : "+v"(acc), "+v"(a), "+v"(b));
-#else
-    const f32x16 &a = a0, &b = b0;
-#endif
+__device__ __forceinline__ void mma_blk(f32x16& acc, const f32x16& a, const f32x16& b) {
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
 }
 
-// ---- an fp32 block product on the bf16 pipe, exactly (scripts/bench_split_bf16.hip) -- the K^-1 phase of the 8-WAVE build.
+// ---- an fp32 block product on the bf16 pipe, exactly (scripts/bench_split_bf16.hip) -- the K^-1 phase of both builds.
 // An fp32 value is the exact sum of three bf16 values (8 + 8 + 8 significand bits, by truncation); S_A^T S_B as the six plane
 // products a1 b1, a1 b2, a2 b1, a1 b3, a3 b1, a2 b2 on v_mfma_f32_32x32x16_bf16 (fp32 accumulation; what is dropped is below
 // 2^-24 of a product) has the error of the fp32 MFMA product (1.6e-7 against 2.0e-7 of max |result|) at less than half its
 // cycles.  Registers 8m .. 8m+7 of a block in the accumulator layout are the 8-per-lane operand of that MFMA (the same k-slots
 // in A and B); the planes are made in registers from the half block as it was loaded, once for the two products that use it.
-// 8-wave build ONLY (one workgroup per CU, the phase between workgroup barriers: every wave of the CU is in this loop or in the
-// contraction behind it).  In the 4-wave build, beside a second workgroup in another phase, results were no longer reproducible
-// bit for bit (11-420 of 4096 tiles per launch; with the settle pad below still 1 tile in ~10 launches).
+// (Round 3 kept this loop out of the 4-wave build: beside it, 15 of 614 k evaluations of the CO-RESIDENT workgroup came out
+// different from launch to launch.  Root cause, EXPERIMENTS.md E48: not this loop and no hand-off -- the factor was bit-identical
+// in every one of 2 500 dumped events; what differed was ONE term of the diagonal chain's forward-solve sum, lost in lanes 48-63
+// of the low half of a v_pk_fma_f32 that the SLP vectoriser had formed from the two scalar sums.  The fp32 kernels are built
+// with -fno-slp-vectorize since; see the Makefile.)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct RawHalf { u32x4 q[2]; };                  // registers 8m .. 8m+7 of a block, as loaded
 struct HalfPl { u32x4 p[3]; };                   // their three bf16 planes: 8 bf16 per lane and plane
@@ -194,10 +190,11 @@ __device__ __forceinline__ f32x16 mfma_bf(const u32x4& a, const u32x4& b, const 
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// Between the VALU instructions that write the planes and the first MFMA that reads them: 8 wait states.  Without them the
-// MFMA can read a plane register before the split has landed in it -- when the matrix pipe is idle and the MFMA issues at once;
-// behind a busy pipe it never shows (every block product as plane products, 4085 of 4096 tiles irreproducible
-// without this pad, 1 with it; the K^-1 loop below: 11-420 without, 0 with).  hipcc (ROCm 7.2) inserts none here.
+// All planes of a step are made before its first MFMA issues (the asm ties them), and eight idle wait states follow.  This is
+// NOT a hazard workaround: the hardware needs one wait state between a VALU write and v_mfma_f32_32x32x16_bf16 reading the
+// register (two for v_mfma_f32_32x32x2_f32) and hipcc always leaves two (scripts/bench_valu_mfma_hazard.hip: 0 stale reads in
+// 1.3e9 trials per case from one wait state on).  It keeps the 24 MFMAs of a step back to back and costs nothing measurable
+// (round 3's A/B); round 3 read its effect on the E48 flips as a missing wait state -- it only changed the partner's timing.
 #define GPSAT_PLANES_SETTLE(...) asm volatile("s_nop 7" : __VA_ARGS__)
 #define GPSAT_PL(P) "+v"((P).p[0]), "+v"((P).p[1]), "+v"((P).p[2])
 
@@ -798,6 +795,12 @@ __device__ __forceinline__ bool pt_wait_lc(Shared* sh, gCoopCtl* ctl, const int*
 // raised behind a workgroup-scope fence only, which waits for nothing on gfx950).
 #define PT_RELEASE() coop_drain()
 
+#ifdef GPSAT_DUMP       // diagnostic build: stages of the forward-solve partial sums per lane (EXPERIMENTS.md E48), rows < 32
+#define DBG_TP(stage, jr, v) do { if ((jr) < 32) c.ws[(size_t)(c.zb - 8) * BLK + ((stage) * 32 + (jr)) * 64 + lane] = (v); } while (0)
+#else
+#define DBG_TP(stage, jr, v) do {} while (0)
+#endif
+
 // D00 += U_k,j0^T U_k,j0, D01 += U_k,j0^T U_k,j1, D11 += U_k,j1^T U_k,j1 and the forward-solve partials for k in [kb, ke)
 template <int D, int KN>
 __device__ __forceinline__ void chain_kloop(const Ctx<D, KN>& c, const Panel<D>& p, int kb, int ke, f32x16& D00, f32x16& D01,
@@ -852,6 +855,7 @@ __device__ __forceinline__ bool pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const
     __builtin_amdgcn_s_setprio(3);
     TRACE(c, 2, slot);
     chain_kloop<D, KN>(c, p, 0, kwait, D00, D01, D11, tp0, tp1);
+    DBG_TP(0, j0, tp0); DBG_TP(0, j1, tp1);
     TRACE(c, 3, slot);
     if (kwait < j0 && !held) {
         // group 0 of the previous panel is finished by the column wave: wait for its rows
@@ -908,6 +912,7 @@ __device__ __forceinline__ bool pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const
         if (lane == 0) PTS(g0done, slot);
     }
     PROF_END(c, 0);
+    DBG_TP(1, j0, tp0); DBG_TP(1, j1, tp1);
     TRACE(c, 5, slot);
     // the factor copies of this parity still serve the groups of panel slot-2 (cooperative evaluation: every group reads
     // the factors from the workspace, the LDS copies serve this chain alone)
@@ -947,6 +952,7 @@ __device__ __forceinline__ bool pt_chain(Ctx<D, KN>& c, const Panel<D>& p, const
         stl(c.L.LT + (2 * par + r) * BLK, lane, S2);
         // z_jr = X (y_jr - t_jr): lane (h,g) holds X[g][rho(r,h)] in S2
         const float t = xhalf_sum(tp);
+        DBG_TP(2, jr, tp); DBG_TP(3, jr, t);
         if (c.h == 0) lds_f[c.L.tmp + c.g] = lds_f[c.L.y + 32 * jr + c.g] - t;
         wave_lds_sync();
         float zz = 0.f;
@@ -1383,44 +1389,8 @@ __device__ __forceinline__ void grad_group(const Ctx<D, KN>& c, int g, int ia, i
     f32x16 acc[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[n] = zero16();
-#if defined(GPSAT_W8) || defined(GPSAT_KINV_BF16_W4)      // (the macro: developer builds of DESIGN.md E48)
     if (ia == ib) kinv_kloop<true>(c.ws, NB, a0, b0, lane, acc);
     else kinv_kloop<false>(c.ws, NB, a0, b0, lane, acc);
-#else
-    // M_cc,x lives at block cc*NB + x (cc >= x).  First step cc = a0: only row a0 exists (M_a0,a1 = 0)
-    f32x16 A0 = ldg(c.ws, a0 * NB + a0, lane);
-    f32x16 B0 = ldg(c.ws, a0 * NB + b0, lane);
-    f32x16 B1 = ldg(c.ws, use01 ? a0 * NB + b1 : c.zb, lane);
-    f32x16 A1 = A0;
-    if (a0 + 1 < NB) {
-        f32x16 nA0 = ldg(c.ws, a1 * NB + a0, lane);
-        f32x16 nA1 = ldg(c.ws, a1 * NB + a1, lane);
-        f32x16 nB0 = ldg(c.ws, a1 * NB + b0, lane);
-        f32x16 nB1 = ldg(c.ws, hasb1 ? a1 * NB + b1 : c.zb, lane);
-        mma_blk(acc[0], A0, B0);
-        if (use01) mma_blk(acc[1], A0, B1);
-        A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
-        for (int cc = a1; cc + 1 < NB; ++cc) {          // last step peeled, as in pt_group_kloop
-            const int cn = cc + 1;
-            nA0 = ldg(c.ws, cn * NB + a0, lane);
-            nA1 = ldg(c.ws, cn * NB + a1, lane);
-            nB0 = ldg(c.ws, cn * NB + b0, lane);
-            nB1 = ldg(c.ws, hasb1 ? cn * NB + b1 : c.zb, lane);
-            mma_blk(acc[0], A0, B0);
-            if (use01) mma_blk(acc[1], A0, B1);
-            mma_blk(acc[2], A1, B0);
-            if (hasb1) mma_blk(acc[3], A1, B1);
-            A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
-        }
-        mma_blk(acc[0], A0, B0);
-        if (use01) mma_blk(acc[1], A0, B1);
-        mma_blk(acc[2], A1, B0);
-        if (hasb1) mma_blk(acc[3], A1, B1);
-    } else {
-        mma_blk(acc[0], A0, B0);
-        if (use01) mma_blk(acc[1], A0, B1);
-    }
-#endif
     PROF_END(c, 6);
     float accl[D];
 #pragma unroll
@@ -1494,32 +1464,38 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
         if (c.tid == 0 && !coop_close(sh, c.ctl, ngroups)) sh->fail = 2;
         __syncthreads();
     }
-    // fixed-order sum: wave w adds the groups w, w + NW, ... per lane (fp64), then across lanes, then across waves
-    double v[D + 2];
+    // fixed-order sum over eight VIRTUAL waves, whatever the build (the 4-wave build's waves run two each): virtual wave vw adds
+    // the groups vw, vw + 8, ... per lane (fp64), then across lanes; thread 0 adds the eight in order.  The 4-wave and the
+    // 8-wave build thus return the same bits (tests/test_gpu_builds_agree.py): which build runs a tile depends on the batch.
 #pragma unroll
-    for (int i = 0; i < D + 2; ++i) v[i] = 0.0;
-    for (int g = c.w; g < ngroups; g += NW) {
-        const int base = c.gp0 + g * ((D + 2) * 256);
-        float f[D + 2];
+    for (int vv = 0; vv < 8 / NW; ++vv) {
+        const int vw = c.w + NW * vv;
+        double v[D + 2];
 #pragma unroll
-        for (int i = 0; i < D + 2; ++i) f[i] = ld_part(c.ws, base + i * 256, lane);
+        for (int i = 0; i < D + 2; ++i) v[i] = 0.0;
+        for (int g = vw; g < ngroups; g += 8) {
+            const int base = c.gp0 + g * ((D + 2) * 256);
+            float f[D + 2];
 #pragma unroll
-        for (int i = 0; i < D + 2; ++i) v[i] += (double)f[i];
-    }
+            for (int i = 0; i < D + 2; ++i) f[i] = ld_part(c.ws, base + i * 256, lane);
 #pragma unroll
-    for (int i = 0; i < D + 2; ++i) {
+            for (int i = 0; i < D + 2; ++i) v[i] += (double)f[i];
+        }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off);
-    }
-    if (lane == 0) {
+        for (int i = 0; i < D + 2; ++i) {
 #pragma unroll
-        for (int i = 0; i < D + 2; ++i) sh->red[c.w][i] = v[i];
+            for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < D + 2; ++i) sh->red[vw][i] = v[i];
+        }
     }
     __syncthreads();
     if (c.tid == 0) {
         for (int i = 0; i < D + 2; ++i) {
             double s = 0.0;
-            for (int ww = 0; ww < NW; ++ww) s += sh->red[ww][i];
+            for (int ww = 0; ww < 8; ++ww) s += sh->red[ww][i];
             // scaled diff^2 already carries 1/l^2 (dk/dl = g diff^2 / l^3); kf, g are without sf2
             if (i < D) sh->gth[i] = 0.5 * (double)c.sf2 * (s / (double)KScale<KN>::c2) / sh->theta[i];
             else sh->gth[i] = 0.5 * s;
@@ -1532,15 +1508,20 @@ __device__ __forceinline__ void phase_grad(Ctx<D, KN>& c) {
 template <int D, int KN>
 __device__ __forceinline__ void finish_nll(Ctx<D, KN>& c) {
     Shared* sh = shared_state();
-    double q = 0.0;
-    for (int p = c.tid; p < c.N; p += NT) { const double zz = (double)lds_f[c.L.z + p]; q += zz * zz; }
+    // eight virtual waves of 64 lanes, whatever the build (see phase_grad)
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
-    if (c.lane == 0) sh->red[c.w][7] = q;
+    for (int vv = 0; vv < 8 / NW; ++vv) {
+        const int vw = c.w + NW * vv;
+        double q = 0.0;
+        for (int p = 64 * vw + c.lane; p < c.N; p += 512) { const double zz = (double)lds_f[c.L.z + p]; q += zz * zz; }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
+        if (c.lane == 0) sh->red[vw][7] = q;
+    }
     __syncthreads();
     if (c.tid == 0) {
         double s = 0.0;
-        for (int ww = 0; ww < NW; ++ww) s += sh->red[ww][7];
+        for (int ww = 0; ww < 8; ++ww) s += sh->red[ww][7];
         sh->nll = 0.5 * s + sh->logdet + 0.5 * (double)c.N * 1.8378770664093453;   // log(2 pi)
         sh->gradnext = 0;                  // group queue of the gradient phase
     }
@@ -2118,6 +2099,24 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
             continue;
         }
 
+#ifdef GPSAT_DUMP
+        if (A.dump) {              // diagnostic build: what the last evaluation left behind, per tile
+            __syncthreads();
+            float* dp = A.dump + (size_t)t * A.dump_stride;
+            const int nblk = NB * NB + NB;
+            for (int bq = c.w; bq < nblk; bq += NW) { const f32x16 v = ldg(c.ws, bq, c.lane); stg(dp, bq, c.lane, v); }
+            for (int i = c.tid; i < c.Npad; i += NT) {
+                dp[(size_t)nblk * BLK + i] = lds_f[c.L.z + i];
+                dp[(size_t)nblk * BLK + c.Npad + i] = lds_f[c.L.alpha + i];
+            }
+            if (c.tid == 0) *reinterpret_cast<double*>(dp + (size_t)nblk * BLK + 2 * c.Npad) = sh->logdet;
+            // the chain's staged partial sums (DBG_TP): the 8 blocks in front of the zero block
+            for (int i = c.tid; i < 8 * BLK; i += NT)
+                dp[(size_t)nblk * BLK + 2 * c.Npad + 16 + i] = c.ws[(size_t)(c.zb - 8) * BLK + i];
+            coop_drain();
+            __syncthreads();
+        }
+#endif
         // ================= outputs + prediction from the factorisation at the accepted parameters
         if (c.tid == 0) {
             int st = sh->status;

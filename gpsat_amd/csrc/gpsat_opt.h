@@ -20,7 +20,7 @@ struct Shared {
     double gth[HMAX];          // dNLL/dtheta
     double nll;
     double logdet;
-    double red[NW][8];
+    double red[8][8];          // partial sums of eight VIRTUAL waves (the 4-wave builds run two each): same sums in every build
     // optimiser state (thread 0 writes, everybody reads after a barrier)
     double lo[HMAX], hi[HMAX], shift[HMAX];
     double u[HMAX], g[HMAX], f;            // current accepted point (u-space)
