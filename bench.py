@@ -364,6 +364,8 @@ def main():
     ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs4", "f64fit"])
     ap.add_argument("--no-sklearn", action="store_true", help="skip the scikit-learn line of the CPU baseline")
     ap.add_argument("--no-quality", action="store_true", help="skip the result-quality block (fp64 converged reference run)")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the two-step runs of configs[2], configs[4] per GPU and the "
+                    "fp64 fit that follow the headline's timed region")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -390,6 +392,21 @@ def main():
 
     # ---- host-side work that forks worker processes happens BEFORE the GPU / RCCL are initialised
     w = build_workload(a, rank, world, workers)
+    # the other single-GPU configurations of BASELINE.json, measured after the headline's timed region:
+    # their tiles are generated here, before the GPU is initialised (the generators fork)
+    others = {}
+    if rank == 0 and world == 1 and a.workload == "configs1" and a.global_tiles == 0 and not a.no_other_workloads and not a.exact_iters:
+        import copy
+        for key, tiles in (("configs2", 4096), ("configs4", 1024), ("f64fit", a.tiles)):
+            if key == "f64fit":
+                ow = dict(w)
+                ow.update(name="BASELINE.json configs[1]'s tiles in fp64 (GPflow default_float): RBF, 3D inputs, fit + predict",
+                          key="f64fit", dtype="f64", np_dt=np.float64, peak=PEAK_F64_MFMA_TFLOPS)
+            else:
+                oa = copy.copy(a)
+                oa.workload, oa.tiles = key, tiles
+                ow = build_workload(oa, rank, world, workers)
+            others[key] = ow
     cpu = None
     if rank == 0 and world == 1 and a.cpu_tiles != 0 and workers > 1:
         cpu = cpu_baseline(w, a, workers)
@@ -493,6 +510,41 @@ def main():
     if cpu is not None:
         cpu.pop("_nll", None)
 
+    other_out = {}
+    for key, ow in others.items():
+        # same protocol, two steps each: inputs resident in HBM, kernel time from the library's HIP events
+        oT, oP = ow["T"], ow["P"]
+        o_dt = torch.float32 if ow["dtype"] == "f32" else torch.float64
+        oX, oy, oXs = (torch.from_numpy(np.ascontiguousarray(v, dtype=ow["np_dt"])).to(dev) for v in (ow["X"], ow["y"], ow["Xs"]))
+        ofm = torch.empty(max(oT * oP, 1), dtype=o_dt, device=dev)
+        ofv, oyv = torch.empty_like(ofm), torch.empty_like(ofm)
+        okw = dict(D=ow["D"], obs_off=ow["obs_off"], pred_off=ow["pred_off"], theta0=ow["theta0"], kernel=ow["kernel"],
+                   optimiser=ow["optimiser"], max_iter=ow["max_iter"], dtype=ow["dtype"])
+        if ow["lo"] is not None:
+            okw.update(lo=ow["lo"], hi=ow["hi"])
+        eng.fit_predict_batch(X=oX, y=oy, Xs=oXs, out=(ofm, ofv, oyv), **okw)          # warm-up
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        oks = []
+        for _ in range(2):
+            orr = eng.fit_predict_batch(X=oX, y=oy, Xs=oXs, out=(ofm, ofv, oyv), **okw)
+            oks.append(orr.kernel_ms)
+        torch.cuda.synchronize()
+        odt = time.perf_counter() - t1
+        oN = ow["Ns"].astype(np.float64)
+        if ow["optimiser"] == "none":
+            ofl = float((f_nll(oN, ow["D"]) + f_pred(oN, oP, ow["D"])).sum())
+        else:
+            ofl = float((orr.n_eval.astype(np.float64) * f_eval(oN, ow["D"]) + f_pred(oN, oP, ow["D"])).sum())
+        okm = float(np.mean(oks))
+        other_out[key] = {"workload": ow["name"], "value": round(2 * oT / odt, 2), "unit": "tiles/s", "steps": 2, "dtype": ow["dtype"],
+                          "ms_per_step": round(odt / 2 * 1e3, 3), "kernel_ms": round(okm, 3), "tiles": int(oT),
+                          "obs_per_tile": float(oN.mean()), "evals_per_tile": round(float(orr.n_eval.mean()), 2),
+                          "failed_tiles": int(np.sum((orr.status == 2) | (orr.status == 3))),
+                          "roofline": {"bound": "mfma", "achieved": round(ofl / (okm * 1e-3) / 1e12, 3), "peak": ow["peak"], "unit": "TFLOP/s",
+                                       "frac": round(ofl / (okm * 1e-3) / 1e12 / ow["peak"], 4)}}
+        del oX, oy, oXs, ofm, ofv, oyv
+
     if rank == 0:
         Nf = w["Ns"].astype(np.float64)
         n_eval = r.n_eval.astype(np.float64)
@@ -534,6 +586,8 @@ def main():
             out["cpu_baseline"] = cpu
         if quality is not None:
             out["quality"] = quality
+        if other_out:
+            out["other_workloads"] = other_out
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

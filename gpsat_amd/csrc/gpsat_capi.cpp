@@ -33,6 +33,14 @@ int fail(int code, const std::string& msg) {
                         std::string(#expr) + ": " + hipGetErrorString(e_));                       \
     } while (0)
 
+// Developer knobs (GPSAT_DEBUG_*: grid size, slice length, cooperative-tile modes, team size, statistics) are read ONLY when
+// GPSAT_DEVELOPER=1 is set in the environment: a stray GPSAT_DEBUG_* variable never changes what the shipped library does.
+inline const char* dev_env(const char* name) {
+    const char* d = std::getenv("GPSAT_DEVELOPER");
+    if (!d || d[0] != '1' || d[1] != '\0') return nullptr;
+    return std::getenv(name);
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -53,6 +61,22 @@ struct DevBuf {
 
 }  // namespace
 
+// FNV-1a over all of `refs` and a sample of at most 65 536 evenly spaced elements of `points` (plus both ends): a caller who
+// refills the same host buffers between the sizes call and the fill call gets a fresh selection, not the cached one
+static unsigned long long sel_fingerprint(const double* points, long long nP, const double* refs, long long nR) {
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&](const double* p) {
+        unsigned long long v;
+        std::memcpy(&v, p, 8);
+        h = (h ^ v) * 1099511628211ull;
+    };
+    for (long long i = 0; i < nR; ++i) mix(refs + i);
+    const long long step = std::max<long long>(1, nP / 65536);
+    for (long long i = 0; i < nP; i += step) mix(points + i);
+    for (long long i = std::max<long long>(0, nP - 64); i < nP; ++i) mix(points + i);
+    return h;
+}
+
 struct gpsat_handle {
     int device = 0;
     int num_cu = 0;
@@ -70,6 +94,7 @@ struct gpsat_handle {
         int64_t M = 0, total = -1;
         int C = 0, T = 0;
         gpsat_select_spec sp;
+        unsigned long long fp = 0;     // fingerprint of the tables' CONTENTS at the sizes call
         const int* d_result = nullptr;
         std::vector<int64_t> off;
     } selc;
@@ -160,6 +185,7 @@ int gpsat_last_timing(gpsat_handle* h, double* kernel_ms, double* total_ms) {
 
 int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     if (!h || !b) return fail(GPSAT_EINVAL, "gpsat_fit_predict_batch: NULL handle or batch");
+    h->selc.total = -1;               // any other call on the handle ends a pending two-call selection
     if (b->T < 0) return fail(GPSAT_EINVAL, "T < 0");
     if (b->T == 0) return GPSAT_OK;
     if (b->D < 1 || b->D > 4) return fail(GPSAT_EINVAL, "D must be 1..4 in this build");
@@ -243,7 +269,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     // teams (fp64 kernels, 8-wave build): with few large tiles, G workgroups run every tile together (gpsat_kernels_f64.hip)
     int team = 1;
     if (f64 && !d4 && NBmax >= 64 && 2 * T <= h->num_cu) team = std::min(16, h->num_cu / T);
-    if (const char* e = std::getenv("GPSAT_DEBUG_TEAM")) { if (f64 && !d4) team = std::max(1, std::min(32, std::atoi(e))); }
+    if (const char* e = dev_env("GPSAT_DEBUG_TEAM")) { if (f64 && !d4) team = std::max(1, std::min(32, std::atoi(e))); }
     if (h->force_solo) team = 1;
     if (team > 1) grid = std::min(T, std::max(1, h->num_cu / team)) * team;
     // cooperative tiles (fp32 kernels): a workgroup without a tile helps a running one (gpsat_coop.h).  With fewer tiles than
@@ -251,13 +277,13 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
     bool coop = !f64;
     int coop_min_nb = 12, coop_hdiv = 12;
     int coop_force = 0;
-    if (const char* e = std::getenv("GPSAT_DEBUG_COOP")) {           // developer: 0 = off, 2 = cooperative code path always
+    if (const char* e = dev_env("GPSAT_DEBUG_COOP")) {           // developer: 0 = off, 2 = cooperative code path always
         coop = coop && std::atoi(e) != 0;
         coop_force = std::atoi(e) == 2;
     }
-    if (const char* e = std::getenv("GPSAT_DEBUG_COOP_XCD")) coop_force |= (std::atoi(e) & 3) << 2;   // developer: 1 same-XCD helpers only, 2 others only
-    if (const char* e = std::getenv("GPSAT_DEBUG_COOP_MIN_NB")) coop_min_nb = std::max(2, std::atoi(e));
-    if (const char* e = std::getenv("GPSAT_DEBUG_COOP_HDIV")) coop_hdiv = std::max(1, std::atoi(e));
+    if (const char* e = dev_env("GPSAT_DEBUG_COOP_XCD")) coop_force |= (std::atoi(e) & 3) << 2;   // developer: 1 same-XCD helpers only, 2 others only
+    if (const char* e = dev_env("GPSAT_DEBUG_COOP_MIN_NB")) coop_min_nb = std::max(2, std::atoi(e));
+    if (const char* e = dev_env("GPSAT_DEBUG_COOP_HDIV")) coop_hdiv = std::max(1, std::atoi(e));
     // Helpers must be capacity that would otherwise idle.  8-wave build: one workgroup per CU, a workgroup without a tile
     // leaves its CU empty -- always on.  4-wave build (two workgroups per CU): an idle workgroup's CU-mate already runs 1.4 x
     // faster alone, and a helper takes that back (measured on BASELINE configs[1]: the helped tail is 2 % SLOWER) -- off; a
@@ -272,7 +298,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
         }
         if (T < cap) grid = (int)std::min<long long>(cap, want);
     }
-    if (const char* e = std::getenv("GPSAT_DEBUG_GRID")) grid = std::max(1, std::min(grid, std::atoi(e)));   // developer: fewer resident workgroups
+    if (const char* e = dev_env("GPSAT_DEBUG_GRID")) grid = std::max(1, std::min(grid, std::atoi(e)));   // developer: fewer resident workgroups
     if ((rc = h->ws.reserve((size_t)(grid / team) * wsf * esz))) return rc;      // one workspace per workgroup, or per team
 
     const char *dX = nullptr, *dy = nullptr, *dXs = nullptr;
@@ -329,7 +355,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
         const double tiles_per_wg = (double)T / grid;
         if (T > grid && max_cost * 4.0 * grid <= sum_cost && tiles_per_wg <= 64.0) seg_cost = 4 * (512 / bs) * (512 / bs) * (512 / bs);
         // developer / tests: slice length in NB^3 units (0 = off, 1 = every evaluation), whatever the batch looks like
-        if (const char* e = std::getenv("GPSAT_DEBUG_SEG")) seg_cost = std::max(0, std::atoi(e));
+        if (const char* e = dev_env("GPSAT_DEBUG_SEG")) seg_cost = std::max(0, std::atoi(e));
         if (h->force_unsliced || team > 1) seg_cost = 0;
     }
     unsigned long long* d_ring = nullptr; int* d_ring_ctl = nullptr; unsigned* d_state = nullptr;
@@ -439,7 +465,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
         HIP_TRY(hipMemcpyAsync(team_host.data(), h->coop.p, team_host.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     }
     std::vector<int> coop_host;
-    if (coop && std::getenv("GPSAT_DEBUG_COOP_STATS")) {
+    if (coop && dev_env("GPSAT_DEBUG_COOP_STATS")) {
         coop_host.resize((size_t)grid * 256);
         HIP_TRY(hipMemcpyAsync(coop_host.data(), h->coop.p, (size_t)grid * 1024, hipMemcpyDeviceToHost, h->stream));
     }
@@ -454,7 +480,7 @@ int gpsat_fit_predict_batch(gpsat_handle* h, const gpsat_batch* b) {
                              "flag waits given up %lld, owner waits given up %lld, pivot failures %lld, helper unwinds %lld\n",
                      grid, T, st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
     }
-    if (!team_host.empty() && std::getenv("GPSAT_DEBUG_TEAM_STATS"))
+    if (!team_host.empty() && dev_env("GPSAT_DEBUG_TEAM_STATS"))
         std::fprintf(stderr, "gpsat team 0 (size %d), factorisation, owner thread 0, s_memtime ticks: own work of (A) %d, (A) wait + barrier %d, (B) + barrier %d, "
                              "(C) + barrier %d\n", team, team_host[24], team_host[25], team_host[26], team_host[27]);
     for (size_t g = 0; g < team_host.size() / 64; ++g) {
@@ -518,7 +544,8 @@ int gpsat_select_batch(gpsat_handle* h, const gpsat_select_spec* sp, int64_t M, 
     if (T == 0) return GPSAT_OK;
     if ((M > 0 && !points) || !refs) return fail(GPSAT_EINVAL, "gpsat_select_batch: NULL table");
     if (idx && h->selc.total >= 0 && h->selc.pts == points && h->selc.refs == refs && h->selc.M == M && h->selc.C == C &&
-        h->selc.T == T && std::memcmp(&h->selc.sp, sp, sizeof(*sp)) == 0) {
+        h->selc.T == T && std::memcmp(&h->selc.sp, sp, sizeof(*sp)) == 0 &&
+        h->selc.fp == sel_fingerprint(points, (long long)M * C, refs, (long long)T * C)) {
         const int64_t total = h->selc.total;
         h->selc.total = -1;
         std::memcpy(off, h->selc.off.data(), (size_t)(T + 1) * sizeof(int64_t));
@@ -555,7 +582,7 @@ int gpsat_select_batch(gpsat_handle* h, const gpsat_select_spec* sp, int64_t M, 
     gpsat::BinSpec bin;
     bin.ndim = 0;
     const int* d_perm = nullptr;
-    if (M >= 65536 && !std::getenv("GPSAT_DEBUG_NO_BINNING")) {
+    if (M >= 65536 && !dev_env("GPSAT_DEBUG_NO_BINNING")) {
         auto add_dim = [&](int col, double cell) {
             if (bin.ndim >= 3 || !(cell > 0.0) || !std::isfinite(cell)) return;
             for (int d = 0; d < bin.ndim; ++d) if (bin.col[d] == col) return;
@@ -674,6 +701,7 @@ int gpsat_select_batch(gpsat_handle* h, const gpsat_select_spec* sp, int64_t M, 
         // sizes asked for: the indices stay on the device for the call that follows with the same arguments
         h->selc.pts = points; h->selc.refs = refs; h->selc.M = M; h->selc.C = C; h->selc.T = T; h->selc.sp = *sp;
         h->selc.d_result = d_final; h->selc.total = off[T];
+        h->selc.fp = sel_fingerprint(points, (long long)M * C, refs, (long long)T * C);
         h->selc.off.assign(off, off + T + 1);
     }
     return GPSAT_OK;
@@ -683,6 +711,7 @@ int gpsat_smooth_batch(gpsat_handle* h, int32_t T, const double* x, const double
                        double l_y, double* out) {
     if (!h || T < 0 || (T > 0 && (!x || !y || !vals || !out))) return fail(GPSAT_EINVAL, "gpsat_smooth_batch: bad argument");
     if (!(l_x > 0.0) || !(l_y > 0.0)) return fail(GPSAT_EINVAL, "gpsat_smooth_batch: length scales must be positive");
+    h->selc.total = -1;
     if (T == 0) return GPSAT_OK;
     HIP_TRY(hipSetDevice(h->device));
     int rc;

@@ -24,17 +24,22 @@ typedef __attribute__((address_space(1))) double gdouble;
 enum { COOP_CLOSED = 0, COOP_SWEEP = 1, COOP_GRAD = 2, COOP_RELEASED = 3 };
 
 struct CoopCtl {                  // 1 KiB per workgroup, zeroed by the host before every launch
-    // owner -> helpers (thread 0 of the owner, sc1 stores; polled by helpers)
-    unsigned phase;               // (seq << 2) | kind (COOP_*); seq counts the phases this workgroup has opened
+    // Phase word and check-in count in ONE 64-bit word, changed by single atomics only:
+    //   bits 63..32  (seq << 2) | kind (COOP_*); seq counts the phases this workgroup has opened as an owner
+    //   bits 31..0   helper workgroups checked into the open phase
+    // A helper checks in by compare-and-swap (count + 1 only while the phase half is what it read), the owner closes a phase by
+    // an atomic AND on the kind bits and then waits for the count half of the SAME word: no pair of words whose accesses could
+    // pass each other (round 3 had `phase` and `active` apart, relaxed: a store-buffering pattern).
+    unsigned long long pa;
     int tile;                     // tile of the running optimisation
     int want_m;                   // the open sweep also builds M = L^-1 (gradient wanted)
     int score;                    // > 0: the running tile takes helpers (NB of the tile); 0: not now
     int hcap;                     // helpers wanted at most
-    int pad0[3];
+    int pad0[2];
     double theta[8];              // parameters of the open evaluation
     // counters (agent-scope atomic adds / exchanges only)
     int helpers;                  // attached helper workgroups
-    int active;                   // helper workgroups inside the open phase
+    int unused0;
     int qhead;                    // group queue head of the open phase
     int done;                     // queue groups finished
     int fail;                     // the open evaluation has failed (not positive definite, or a spin gave up)
@@ -57,6 +62,10 @@ __device__ __forceinline__ gfloat* as_gfloat(float* p) { return (gfloat*)p; }
 __device__ __forceinline__ gCoopCtl* as_gctl(void* p) { return (gCoopCtl*)p; }
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define RLX_AGENT_CAS __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define PA_PHASE(v) ((unsigned)((v) >> 32))
+#define PA_ACTIVE(v) ((unsigned)(v))
+#define PA_MAKE(seq, kind) ((unsigned long long)(((unsigned)(seq) << 2) | (unsigned)(kind)) << 32)
 #define COOP_STAT(ctl, i) __hip_atomic_fetch_add(&(ctl)->stat[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define RLX_WG __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP
 

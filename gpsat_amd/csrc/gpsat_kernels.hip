@@ -1152,7 +1152,7 @@ __device__ __forceinline__ bool coop_wait_eq(gCoopCtl* ctl, const gint* word, in
     for (int spins = 0; __hip_atomic_load(word, RLX_AGENT) != v; ++spins) {
         __builtin_amdgcn_s_sleep(8);
         if (spins > (1 << 21)) { COOP_STAT(ctl, 4); return false; }
-        if ((spins & 15) == 15 && word != &ctl->active && __hip_atomic_load(&ctl->fail, RLX_AGENT)) return false;
+        if ((spins & 15) == 15 && __hip_atomic_load(&ctl->fail, RLX_AGENT)) return false;
     }
     return true;
 }
@@ -1160,15 +1160,20 @@ __device__ __forceinline__ bool coop_wait_eq(gCoopCtl* ctl, const gint* word, in
 // owner, thread 0: open a phase of the cooperative evaluation (everything the helpers read has been stored and drained)
 __device__ __forceinline__ void coop_open(Shared* sh, gCoopCtl* ctl, int kind) {
     sh->coop_seq += 1;
-    __hip_atomic_store(&ctl->phase, ((unsigned)sh->coop_seq << 2) | (unsigned)kind, RLX_AGENT);
+    __hip_atomic_store(&ctl->pa, PA_MAKE(sh->coop_seq, kind), RLX_AGENT);        // nobody is checked in: the last phase was closed
 }
 
 // owner, thread 0: all `total` queue groups done (or the evaluation failed), then close the phase and wait until the helpers
 // that checked in have checked out.  Returns false when a wait gave up.
 __device__ __forceinline__ bool coop_close(Shared* sh, gCoopCtl* ctl, int total) {
     bool ok = coop_wait_eq(ctl, &ctl->done, total);
-    __hip_atomic_store(&ctl->phase, ((unsigned)sh->coop_seq << 2) | (unsigned)COOP_CLOSED, RLX_AGENT);
-    if (!coop_wait_eq(ctl, &ctl->active, 0)) ok = false;
+    // kind -> CLOSED (0) with the count untouched, then the count of the same word (a helper's compare-and-swap either came
+    // before this AND and is counted, or fails on the changed phase half)
+    __hip_atomic_fetch_and(&ctl->pa, ~(3ull << 32), RLX_AGENT);
+    for (int spins = 0; PA_ACTIVE(__hip_atomic_load(&ctl->pa, RLX_AGENT)) != 0u; ++spins) {
+        __builtin_amdgcn_s_sleep(8);
+        if (spins > (1 << 21)) { COOP_STAT(ctl, 4); ok = false; break; }     // never reached by design: a lost helper must not hang the GPU
+    }
     return ok;
 }
 
@@ -1758,16 +1763,17 @@ __device__ __noinline__ void helper_episode(Ctx<D, KN> c, const HelpArgs A) {
             const int b = sh->hp[0];
             if (b >= 0) {
                 gCoopCtl* ctl = ctls + b;
-                const unsigned wd = __hip_atomic_load(&ctl->phase, RLX_AGENT);
+                const unsigned long long pav = __hip_atomic_load(&ctl->pa, RLX_AGENT);
+                const unsigned wd = PA_PHASE(pav);
                 const int kind = (int)(wd & 3u), seq = (int)(wd >> 2);
                 if (kind == COOP_RELEASED || __hip_atomic_load(&ctl->score, RLX_AGENT) <= 0) {
                     __hip_atomic_fetch_add(&ctl->helpers, -1, RLX_AGENT);
                     sh->hp[0] = -1;
                 } else if ((kind == COOP_SWEEP || kind == COOP_GRAD) && seq != sh->hp[1]) {
-                    __hip_atomic_fetch_add(&ctl->active, 1, RLX_AGENT);
-                    if (__hip_atomic_load(&ctl->phase, RLX_AGENT) != wd) {
-                        __hip_atomic_fetch_add(&ctl->active, -1, RLX_AGENT);       // closed meanwhile: not ours
-                    } else {
+                    // check in: count + 1 while the whole word is what was read (a closed or reopened phase, or another helper's
+                    // check-in, makes it fail: look again in the next episode)
+                    unsigned long long expect = pav;
+                    if (__hip_atomic_compare_exchange_strong(&ctl->pa, &expect, pav + 1ull, RLX_AGENT_CAS)) {
                         decision = kind;
                         sh->hp[1] = seq;
                         sh->hp[3] = __hip_atomic_load(&ctl->tile, RLX_AGENT);
@@ -1836,7 +1842,7 @@ __device__ __noinline__ void helper_episode(Ctx<D, KN> c, const HelpArgs A) {
     }
     coop_drain();
     __syncthreads();
-    if (c.tid == 0) __hip_atomic_fetch_add(&c.ctl->active, -1, RLX_AGENT);
+    if (c.tid == 0) __hip_atomic_fetch_add(&c.ctl->pa, ~0ull, RLX_AGENT);          // check out: count - 1
     __syncthreads();
 }
 
@@ -2042,12 +2048,12 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
         const bool helpable = coop_on && NB >= A.coop_min_nb;
         if (c.tid == 0) {
             sh->hp[2] = -1;                        // the coordinates in LDS are this tile's, not a helped one's
-            if (coop_on) sh->coop_seq = (int)(__hip_atomic_load(&ctl_own->phase, RLX_AGENT) >> 2);
+            if (coop_on) sh->coop_seq = (int)(PA_PHASE(__hip_atomic_load(&ctl_own->pa, RLX_AGENT)) >> 2);
             if (helpable) {
                 // helpers wanted: one per coop_hdiv block columns (the bulk queue of a panel has NB / 2 groups), 7 at most
                 __hip_atomic_store(&ctl_own->tile, t, RLX_AGENT);
                 __hip_atomic_store(&ctl_own->hcap, min(7, max(1, NB / A.coop_hdiv)), RLX_AGENT);
-                __hip_atomic_store(&ctl_own->phase, ((unsigned)sh->coop_seq << 2) | (unsigned)COOP_CLOSED, RLX_AGENT);
+                __hip_atomic_store(&ctl_own->pa, PA_MAKE(sh->coop_seq, COOP_CLOSED), RLX_AGENT);
                 __hip_atomic_store(&ctl_own->score, NB, RLX_AGENT);
             }
         }
@@ -2084,7 +2090,7 @@ __global__ void __launch_bounds__(NT, GPSAT_MIN_WG) gp_tile_kernel(const KernelA
         if (helpable && c.tid == 0) {
             // no more cooperative phases from this tile: its helpers look elsewhere (the prediction is the owner's alone)
             __hip_atomic_store(&ctl_own->score, 0, RLX_AGENT);
-            __hip_atomic_store(&ctl_own->phase, ((unsigned)sh->coop_seq << 2) | (unsigned)COOP_RELEASED, RLX_AGENT);
+            __hip_atomic_store(&ctl_own->pa, PA_MAKE(sh->coop_seq, COOP_RELEASED), RLX_AGENT);
         }
         if (suspended) {
             unsigned* dst = A.state + (size_t)t * A.state_words;

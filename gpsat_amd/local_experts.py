@@ -358,8 +358,8 @@ class ResultStore:
         return parts, marks
 
     def drop_uncommitted(self):
-        """Remove part files of this rank that no marker commits (left by a run that died during a flush), and stale
-        temporaries of processes that no longer exist."""
+        """Remove part files of this rank that no marker commits (left by a run that died during a flush), and this rank's
+        stale temporaries."""
         if not self.path:
             return
         parts, marks = self._scan()
@@ -367,18 +367,29 @@ class ResultStore:
             for k, r, f in plist:
                 if r == self.rank and (k, r) not in marks:
                     os.remove(os.path.join(self.path, f))
+        # temporaries carry their writer's RANK (`.tmp.r<rank>.<pid>.<name>`): a rank only ever removes its own -- ranks that
+        # share the directory from different PID namespaces or hosts (one container per rank, NFS) cannot see each other's
+        # PIDs, and a late starter must not delete another rank's file in flight.  Temporaries of older versions
+        # (`.tmp.<pid>.<name>`) are removed once they are an hour old.
+        mine = f".tmp.r{self.rank}."
         for f in os.listdir(self.path):
-            if f.startswith(".tmp."):
-                pid = f.split(".")[2]
-                alive = pid.isdigit() and os.path.exists(f"/proc/{pid}") and int(pid) != os.getpid()
-                if not alive:
-                    try:
-                        os.remove(os.path.join(self.path, f))
-                    except FileNotFoundError:
-                        pass
+            stale = False
+            if f.startswith(mine):
+                pid = f[len(mine):].split(".")[0]
+                stale = not (pid.isdigit() and int(pid) == os.getpid())
+            elif f.startswith(".tmp.") and not f.startswith(".tmp.r"):
+                try:
+                    stale = time.time() - os.path.getmtime(os.path.join(self.path, f)) > 3600.0
+                except OSError:
+                    stale = False
+            if stale:
+                try:
+                    os.remove(os.path.join(self.path, f))
+                except FileNotFoundError:
+                    pass
 
     def _atomic_write(self, df, name):
-        tmp = os.path.join(self.path, f".tmp.{os.getpid()}.{name}")
+        tmp = os.path.join(self.path, f".tmp.r{self.rank}.{os.getpid()}.{name}")
         if name.endswith(".parquet"):
             df.to_parquet(tmp, engine="pyarrow", index=True)
         else:

@@ -201,6 +201,11 @@ typedef struct gpsat_select_spec {
  * off  : host out [T+1] CSR offsets (always written).
  * idx  : host out [capacity] selected row indices per expert, ascending; may be NULL (count only).
  * Returns GPSAT_EINVAL if capacity < off[T] (off is still valid: call again with a larger buffer).
+ * Two-call use (sizes with idx = NULL, then the same arguments with idx): the indices of the first call stay on the device
+ * and the second call only copies them out -- PROVIDED `points` and `refs` are the same buffers with unchanged contents and
+ * no other call was made on the handle in between.  The library checks the arguments and a fingerprint of the contents (all
+ * of refs, a sample of points) and selects again when anything differs; do not rely on the sample to catch a partial refill
+ * of `points`.
  */
 int gpsat_select_batch(gpsat_handle *h, const gpsat_select_spec *spec, int64_t M, int32_t C, const double *points,
                        int32_t T, const double *refs, int64_t *off, int32_t *idx, int64_t capacity);

@@ -2,6 +2,7 @@
 """Developer: cooperative tiles on / off (GPSAT_DEBUG_COOP) on the same batch: same bytes?  time?"""
 import hashlib
 import os
+os.environ.setdefault("GPSAT_DEVELOPER", "1")     # GPSAT_DEBUG_* knobs are read in developer mode only
 import sys
 import time
 

@@ -4,7 +4,7 @@ set -e
 TAG=$1; shift
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $OUT/raw -- python3 $ROOT/bench.py --cpu-tiles 0 --workers 1 --no-host-leg $BENCH_ARGS --steps 1 --warmup 0 > $OUT/log.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $OUT/raw -- python3 $ROOT/bench.py --cpu-tiles 0 --workers 1 --no-host-leg --no-other-workloads $BENCH_ARGS --steps 1 --warmup 0 > $OUT/log.txt 2>&1
 cd $ROOT
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys

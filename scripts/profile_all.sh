@@ -12,7 +12,7 @@ for WL in $WLS; do
   OUT=$ROOT/gpurun_out/$TAG/$WL; mkdir -p $OUT
   MFMA=SQ_INSTS_VALU_MFMA_F32; PAT=gp_tile_kernel; ST="--steps 3 --warmup 1"; ONE="--steps 1 --warmup 0"
   case $WL in
-    configs1) CMD="$ROOT/bench.py --cpu-tiles 0 --workers 1 --no-host-leg --no-quality";;
+    configs1) CMD="$ROOT/bench.py --cpu-tiles 0 --workers 1 --no-host-leg --no-quality --no-other-workloads";;
     configs2) CMD="$ROOT/bench.py --cpu-tiles 0 --workers 1 --no-host-leg --no-quality --workload configs2";;
     configs2_1024) CMD="$ROOT/bench.py --cpu-tiles 0 --workers 1 --no-host-leg --no-quality --workload configs2 --tiles 1024";;
     configs4) CMD="$ROOT/bench.py --cpu-tiles 0 --workers 1 --no-host-leg --no-quality --workload configs4"; MFMA=SQ_INSTS_VALU_MFMA_F64;;

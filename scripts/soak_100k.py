@@ -2,6 +2,7 @@
 """Developer: the same 100 000-tile batch (N = 500, the configs[3] test's data) run REPS times; every run is compared with the
 first, mismatching tiles are counted and described.  GPSAT_LIB / GPSAT_DEBUG_* select the build and the scheduling."""
 import os
+os.environ.setdefault("GPSAT_DEVELOPER", "1")     # GPSAT_DEBUG_* knobs are read in developer mode only
 import sys
 
 import numpy as np

@@ -3,6 +3,7 @@
 tiles on, every run compared with ONE run with them off: differing tiles are counted and described."""
 import argparse
 import os
+os.environ.setdefault("GPSAT_DEVELOPER", "1")     # GPSAT_DEBUG_* knobs are read in developer mode only
 import sys
 
 import numpy as np

@@ -2,6 +2,7 @@
 """Developer: fp64 teams on / off (GPSAT_DEBUG_TEAM=1 = one workgroup per tile) on the same batch: same bytes?  time?"""
 import hashlib
 import os
+os.environ.setdefault("GPSAT_DEVELOPER", "1")     # GPSAT_DEBUG_* knobs are read in developer mode only
 import sys
 
 import numpy as np

@@ -2,6 +2,7 @@
 """Developer: where a team's time goes -- one evaluation of one fp64 tile with and without the gradient half, with and without
 prediction points, team sizes 1 / 2 / 4 / 8 / 16 (kernel ms)."""
 import os
+os.environ.setdefault("GPSAT_DEVELOPER", "1")     # GPSAT_DEBUG_* knobs are read in developer mode only
 import sys
 
 import numpy as np

@@ -85,3 +85,17 @@ def test_product_package_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "gp_oracle" not in txt, f
+
+
+def test_developer_knobs_are_gated():
+    """No environment variable changes what the shipped library does unless GPSAT_DEVELOPER=1 is set: every GPSAT_DEBUG_*
+    knob goes through dev_env(), and the only plain getenv in the native sources is the one that reads GPSAT_DEVELOPER."""
+    src = os.path.join(ROOT, "gpsat_amd", "csrc")
+    plain = []
+    for f in os.listdir(src):
+        if f.endswith((".cpp", ".hip", ".h")):
+            for ln, line in enumerate(open(os.path.join(src, f)), 1):
+                if "getenv(" in line and "dev_env(" not in line.split("getenv(")[0][-12:]:
+                    plain.append((f, ln, line.strip()))
+    assert all('"GPSAT_DEVELOPER"' in l or "return std::getenv(name)" in l for _, _, l in plain), plain
+    assert len(plain) == 2, plain

@@ -75,3 +75,18 @@ def test_full_size_distribution_fp32_vs_fp64_converged():
                 assert mx <= 3e-3 and mn >= -2e-5, (which, mx, mn)
     # the early stop of the bench's settings costs almost nothing against running fp32 to convergence
     assert abs(float(r_a.n_eval.mean()) - float(r_b.n_eval.mean())) < 1.5
+    # ---- an ORACLE value enters the full-size check: 64 of the 4096 tiles, objective and predictions of
+    # the fp64 oracle AT THE PARAMETERS THE GPU RETURNED, against the bench-settings fp32 run (stated fp64 -> fp32 bounds of
+    # tests/test_gpu_parity.py) and the fp64 run (1e-9 relative)
+    from oracle import gp_oracle as go
+    with threadpool_limits(4):
+        for t in range(17, T, 64):
+            Xt, yt, Xst = (X[t * N:(t + 1) * N].astype(np.float64), y[t * N:(t + 1) * N].astype(np.float64),
+                           Xs[t * P:(t + 1) * P].astype(np.float64))
+            for r, tol_nll, tol_f, tol_v in ((r_a, 2e-5 * N, 2e-3, 2e-3), (r_c, 1e-9, 1e-8, 1e-8)):
+                f, _ = go.nll_and_grad(kid, Xt, yt, r.theta[t], want_grad=False)
+                fm, fv, _ = go.predict(kid, Xt, yt, Xst, r.theta[t])
+                scale_nll = 1.0 if r is r_a else abs(f)
+                assert abs(r.nll[t] - f) <= tol_nll * scale_nll + 2e-6 * abs(f) * (r is r_a), (t, r.nll[t], f)
+                assert np.max(np.abs(np.asarray(r.f_mean[t * P:(t + 1) * P], dtype=np.float64) - fm)) <= tol_f * ymax[t]
+                assert np.max(np.abs(np.asarray(r.f_var[t * P:(t + 1) * P], dtype=np.float64) - fv)) <= tol_v * r.theta[t, D] + 1e-6 * (r is r_a)

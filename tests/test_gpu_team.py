@@ -11,6 +11,7 @@ import pytest
 from gpsat_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
+os.environ["GPSAT_DEVELOPER"] = "1"       # the GPSAT_DEBUG_* knobs used below are read in developer mode only
 
 
 @pytest.fixture(scope="module")

@@ -208,11 +208,17 @@ def test_store_is_parquet_and_reads_older_pickle_stores(tmp_path):
     _assert_same_tables(full, {k: v for k, v in get_results(st2).items() if k in full}, ignore=())
     # a truncated temporary left by a crash: ignored by readers even when a marker for its wave exists,
     # removed by the next drop_uncommitted
-    tmpf = os.path.join(store, ".tmp.999999999.preds.w000001.r000.parquet")
-    open(tmpf, "wb").write(b"trunc")
-    assert ".tmp.999999999.preds" not in get_results(store) and set(ResultStore(store).table_names()) >= set(full)
+    tmpf = os.path.join(store, ".tmp.r0.999999999.preds.w000001.r000.parquet")
+    other = os.path.join(store, ".tmp.r1.999999999.preds.w000001.r001.parquet")      # ANOTHER rank's temporary, maybe in flight
+    old = os.path.join(store, ".tmp.999999999.preds.w000001.r000.parquet")           # an older version's, long dead
+    for f_ in (tmpf, other, old):
+        open(f_, "wb").write(b"trunc")
+    os.utime(old, (1.0e9, 1.0e9))
+    assert ".tmp.r0.999999999.preds" not in get_results(store) and set(ResultStore(store).table_names()) >= set(full)
     ResultStore(store).drop_uncommitted()
-    assert not os.path.exists(tmpf)
+    assert not os.path.exists(tmpf) and not os.path.exists(old)
+    assert os.path.exists(other), "a rank must not remove another rank's temporaries (their PIDs may be invisible here)"
+    os.remove(other)
     out = export_parquet(store, str(tmp_path / "export"))
     got = {os.path.basename(f)[:-8]: pd.read_parquet(f) for f in out}
     _assert_same_tables(full, {k: v for k, v in got.items() if k in full}, ignore=())
