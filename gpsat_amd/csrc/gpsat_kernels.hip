@@ -208,6 +208,36 @@ __device__ __forceinline__ void mma_half(f32x16& acc, const HalfPl& A, const Hal
     acc = mfma_bf(A.p[0], B.p[0], acc);
 }
 
+// The k-loop of a K^-1 group on the bf16 pipe: half blocks (16 k-rows) per step, the halves of step h + 1 in
+// flight while the halves of step h are split into planes and multiplied (24 MFMAs; 18 on the diagonal, where B = A and the
+// upper product is not needed).  Two operand sets in ping-pong (m = 0 / m = 1 of a block row): no register copies.
+struct KinvOps { RawHalf A0, A1, B0, B1; };
+
+template <bool DIAG>
+__device__ __forceinline__ void kinv_comp(f32x16 (&acc)[4], const KinvOps& S) {
+    HalfPl A0 = split_half(S.A0), A1 = split_half(S.A1);
+    if (DIAG) {
+        GPSAT_PLANES_SETTLE(GPSAT_PL(A0), GPSAT_PL(A1));
+#define GPSAT_PP(i, j)                              \
+        acc[0] = mfma_bf(A0.p[i], A0.p[j], acc[0]); \
+        acc[2] = mfma_bf(A1.p[i], A0.p[j], acc[2]); \
+        acc[3] = mfma_bf(A1.p[i], A1.p[j], acc[3]);
+        GPSAT_PP(1, 1) GPSAT_PP(0, 2) GPSAT_PP(2, 0) GPSAT_PP(0, 1) GPSAT_PP(1, 0) GPSAT_PP(0, 0)
+#undef GPSAT_PP
+    } else {
+        HalfPl B0 = split_half(S.B0), B1 = split_half(S.B1);
+        GPSAT_PLANES_SETTLE(GPSAT_PL(A0), GPSAT_PL(A1), GPSAT_PL(B0), GPSAT_PL(B1));
+#define GPSAT_PP(i, j)                              \
+        acc[0] = mfma_bf(A0.p[i], B0.p[j], acc[0]); \
+        acc[1] = mfma_bf(A0.p[i], B1.p[j], acc[1]); \
+        acc[2] = mfma_bf(A1.p[i], B0.p[j], acc[2]); \
+        acc[3] = mfma_bf(A1.p[i], B1.p[j], acc[3]);
+        GPSAT_PP(1, 1) GPSAT_PP(0, 2) GPSAT_PP(2, 0) GPSAT_PP(0, 1) GPSAT_PP(1, 0) GPSAT_PP(0, 0)
+#undef GPSAT_PP
+    }
+}
+
+
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll
@@ -640,29 +670,26 @@ __device__ __forceinline__ void pt_group_kloop(const Ctx<D, KN>& c, const Panel<
     const int kmin = min(ks0, ks1);
 #pragma unroll
     for (int n = 0; n < 4; ++n) W[n] = zero16();
+    // Exact three-plane bf16 products (see mma_half / kinv_comp): half blocks of 16 k-rows per step, the halves of the next
+    // step in flight, two operand sets in ping-pong (no register copies), 24 v_mfma_f32_32x32x16_bf16 per half step where
+    // the fp32 pipe took 32 v_mfma_f32_32x32x2_f32 of twice the length (round 4: configs[1] 55.5 -> 61 % of the fp32 peak,
+    // parity bounds unchanged).  The rows of a block column arrive in order, so a loop may start before its panel's chain is done.
     if (kmin < j0) {
-        f32x16 A0 = ldg(c.ws, kmin * NB + j0, lane);
-        f32x16 A1 = ldg(c.ws, p.has1 ? kmin * NB + p.j1 : c.zb, lane);
-        f32x16 B0 = ldg(c.ws, (kmin >= ks0) ? kmin * NB + c0 : c.zb, lane);
-        f32x16 B1 = ldg(c.ws, (kmin >= ks1) ? kmin * NB + c1 : c.zb, lane);
-        // the last step is peeled: inside the loop the next operands are loaded unconditionally (a conditional load made
-        // the compiler copy the current set into the next one first: 128 instead of 64 register copies per step)
-        for (int k = kmin; k + 1 < j0; ++k) {
-            const int kn = k + 1;
-            const f32x16 nA0 = ldg(c.ws, kn * NB + j0, lane);
-            const f32x16 nA1 = ldg(c.ws, p.has1 ? kn * NB + p.j1 : c.zb, lane);
-            const f32x16 nB0 = ldg(c.ws, (kn >= ks0) ? kn * NB + c0 : c.zb, lane);
-            const f32x16 nB1 = ldg(c.ws, (kn >= ks1) ? kn * NB + c1 : c.zb, lane);
-            mma_blk(W[0], A0, B0);
-            mma_blk(W[1], A0, B1);
-            mma_blk(W[2], A1, B0);
-            mma_blk(W[3], A1, B1);
-            A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
+        const int a1b = p.has1 ? 1 : 0;
+        auto load = [&](KinvOps& S, int k, int m) {
+            S.A0 = ldg_half(c.ws, k * NB + j0, m, lane);
+            S.A1 = ldg_half(c.ws, a1b ? k * NB + p.j1 : c.zb, m, lane);
+            S.B0 = ldg_half(c.ws, (k >= ks0) ? k * NB + c0 : c.zb, m, lane);
+            S.B1 = ldg_half(c.ws, (k >= ks1) ? k * NB + c1 : c.zb, m, lane);
+        };
+        KinvOps S0, S1;
+        load(S0, kmin, 0);
+        for (int k = kmin; k < j0; ++k) {
+            load(S1, k, 1);
+            kinv_comp<false>(W, S0);
+            load(S0, min(k + 1, j0 - 1), 0);          // past the end: the last row again, unused
+            kinv_comp<false>(W, S1);
         }
-        mma_blk(W[0], A0, B0);
-        mma_blk(W[1], A0, B1);
-        mma_blk(W[2], A1, B0);
-        mma_blk(W[3], A1, B1);
     }
     // U-type: W = K - acc ; M-type: W = -acc
     if (v0 && u0) {
@@ -808,23 +835,35 @@ __device__ __forceinline__ void chain_kloop(const Ctx<D, KN>& c, const Panel<D>&
     const int NB = c.NB, lane = c.lane, j0 = p.j0, j1 = p.j1;
     const bool has1 = p.has1 != 0;
     if (kb >= ke) return;
-    f32x16 A0 = ldg(c.ws, kb * NB + j0, lane);
-    f32x16 A1 = ldg(c.ws, has1 ? kb * NB + j1 : c.zb, lane);
-    for (int k = kb; k < ke; ++k) {
-        // the operands of the step after the last are a (harmless) reload of the last: no conditional load, no copy-first
-        const int kn = min(k + 1, ke - 1);
-        const f32x16 nA0 = ldg(c.ws, kn * NB + j0, lane);
-        const f32x16 nA1 = ldg(c.ws, has1 ? kn * NB + j1 : c.zb, lane);
-        mma_blk(D00, A0, A0);
-        mma_blk(D01, A0, A1);
-        mma_blk(D11, A1, A1);
+    // three-plane bf16 products (see pt_group_kloop): per half step 18 MFMAs (D00, D01, D11), the forward-solve sums from the
+    // fp32 halves as they were loaded
+    auto load = [&](RawHalf& a0, RawHalf& a1, int k, int m) {
+        a0 = ldg_half(c.ws, k * NB + j0, m, lane);
+        a1 = ldg_half(c.ws, has1 ? k * NB + j1 : c.zb, m, lane);
+    };
+    auto comp = [&](const RawHalf& a0, const RawHalf& a1, int k, int m) {
+        HalfPl P0 = split_half(a0), P1 = split_half(a1);
+        GPSAT_PLANES_SETTLE(GPSAT_PL(P0), GPSAT_PL(P1));
+#define GPSAT_PP(i, j)                          \
+        D00 = mfma_bf(P0.p[i], P0.p[j], D00);   \
+        D01 = mfma_bf(P0.p[i], P1.p[j], D01);   \
+        D11 = mfma_bf(P1.p[i], P1.p[j], D11);
+        GPSAT_PP(1, 1) GPSAT_PP(0, 2) GPSAT_PP(2, 0) GPSAT_PP(0, 1) GPSAT_PP(1, 0) GPSAT_PP(0, 0)
+#undef GPSAT_PP
 #pragma unroll
-        for (int qq = 0; qq < 16; ++qq) {
-            const float zk = lds_f[c.L.z + 32 * k + rho(qq, c.h)];
-            tp0 = fmaf(A0[qq], zk, tp0);
-            tp1 = fmaf(A1[qq], zk, tp1);
+        for (int q = 0; q < 8; ++q) {
+            const float zk = lds_f[c.L.z + 32 * k + rho(8 * m + q, c.h)];
+            tp0 = fmaf(__uint_as_float(a0.q[q >> 2][q & 3]), zk, tp0);
+            tp1 = fmaf(__uint_as_float(a1.q[q >> 2][q & 3]), zk, tp1);
         }
-        A0 = nA0; A1 = nA1;
+    };
+    RawHalf x0, x1, y0, y1;
+    load(x0, x1, kb, 0);
+    for (int k = kb; k < ke; ++k) {
+        load(y0, y1, k, 1);
+        comp(x0, x1, k, 0);
+        load(x0, x1, min(k + 1, ke - 1), 0);          // past the end: the last row again, unused
+        comp(y0, y1, k, 1);
     }
 }
 
@@ -1306,11 +1345,7 @@ __device__ __forceinline__ float ld_part(const float* __restrict__ ws, int byte_
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, byte_off, GPSAT_LD_AUX));
 }
 
-// The k-loop of a K^-1 group on the bf16 pipe: half blocks (16 k-rows) per step, the halves of step h + 1 in
-// flight while the halves of step h are split into planes and multiplied (24 MFMAs; 18 on the diagonal, where B = A and the
-// upper product is not needed).  Two operand sets in ping-pong (m = 0 / m = 1 of a block row): no register copies.
-struct KinvOps { RawHalf A0, A1, B0, B1; };
-
+// (KinvOps / kinv_comp: next to mma_half above)
 template <bool DIAG>
 __device__ __forceinline__ void kinv_load(KinvOps& S, const float* __restrict__ ws, int NB, int cc, int m, int a0, int b0, int lane) {
     S.A0 = ldg_half(ws, cc * NB + a0, m, lane);
@@ -1318,30 +1353,6 @@ __device__ __forceinline__ void kinv_load(KinvOps& S, const float* __restrict__ 
     if (!DIAG) {
         S.B0 = ldg_half(ws, cc * NB + b0, m, lane);
         S.B1 = ldg_half(ws, cc * NB + b0 + 1, m, lane);
-    }
-}
-
-template <bool DIAG>
-__device__ __forceinline__ void kinv_comp(f32x16 (&acc)[4], const KinvOps& S) {
-    HalfPl A0 = split_half(S.A0), A1 = split_half(S.A1);
-    if (DIAG) {
-        GPSAT_PLANES_SETTLE(GPSAT_PL(A0), GPSAT_PL(A1));
-#define GPSAT_PP(i, j)                              \
-        acc[0] = mfma_bf(A0.p[i], A0.p[j], acc[0]); \
-        acc[2] = mfma_bf(A1.p[i], A0.p[j], acc[2]); \
-        acc[3] = mfma_bf(A1.p[i], A1.p[j], acc[3]);
-        GPSAT_PP(1, 1) GPSAT_PP(0, 2) GPSAT_PP(2, 0) GPSAT_PP(0, 1) GPSAT_PP(1, 0) GPSAT_PP(0, 0)
-#undef GPSAT_PP
-    } else {
-        HalfPl B0 = split_half(S.B0), B1 = split_half(S.B1);
-        GPSAT_PLANES_SETTLE(GPSAT_PL(A0), GPSAT_PL(A1), GPSAT_PL(B0), GPSAT_PL(B1));
-#define GPSAT_PP(i, j)                              \
-        acc[0] = mfma_bf(A0.p[i], B0.p[j], acc[0]); \
-        acc[1] = mfma_bf(A0.p[i], B1.p[j], acc[1]); \
-        acc[2] = mfma_bf(A1.p[i], B0.p[j], acc[2]); \
-        acc[3] = mfma_bf(A1.p[i], B1.p[j], acc[3]);
-        GPSAT_PP(1, 1) GPSAT_PP(0, 2) GPSAT_PP(2, 0) GPSAT_PP(0, 1) GPSAT_PP(1, 0) GPSAT_PP(0, 0)
-#undef GPSAT_PP
     }
 }
 
@@ -1605,19 +1616,30 @@ __device__ __forceinline__ void predict_tile(Ctx<D, KN>& c, const float* __restr
         for (int j = 0; j < NB; ++j) {
             f32x16 acc0 = zero16(), acc1 = zero16();
             if (j > 0) {
-                f32x16 A = ldg(c.ws, j, lane);                 // U_0,j
-                f32x16 B0 = ldg(c.ws, v0, lane);
-                f32x16 B1 = ldg(c.ws, v0 + NB, lane);
-                for (int k = 0; k + 1 < j; ++k) {              // last step peeled (see pt_group_kloop)
-                    const f32x16 nA = ldg(c.ws, (k + 1) * NB + j, lane);
-                    const f32x16 nB0 = ldg(c.ws, v0 + k + 1, lane);
-                    const f32x16 nB1 = ldg(c.ws, v0 + NB + k + 1, lane);
-                    mma_blk(acc0, A, B0);
-                    mma_blk(acc1, A, B1);
-                    A = nA; B0 = nB0; B1 = nB1;
+                // three-plane bf16 products (see pt_group_kloop): 12 MFMAs per half step
+                struct PredOps { RawHalf A, B0, B1; };
+                auto load = [&](PredOps& S, int k, int m) {
+                    S.A = ldg_half(c.ws, k * NB + j, m, lane);
+                    S.B0 = ldg_half(c.ws, v0 + k, m, lane);
+                    S.B1 = ldg_half(c.ws, v0 + NB + k, m, lane);
+                };
+                auto comp = [&](const PredOps& S) {
+                    HalfPl A = split_half(S.A), B0 = split_half(S.B0), B1 = split_half(S.B1);
+                    GPSAT_PLANES_SETTLE(GPSAT_PL(A), GPSAT_PL(B0), GPSAT_PL(B1));
+#define GPSAT_PP(i, jj)                                 \
+                    acc0 = mfma_bf(A.p[i], B0.p[jj], acc0); \
+                    acc1 = mfma_bf(A.p[i], B1.p[jj], acc1);
+                    GPSAT_PP(1, 1) GPSAT_PP(0, 2) GPSAT_PP(2, 0) GPSAT_PP(0, 1) GPSAT_PP(1, 0) GPSAT_PP(0, 0)
+#undef GPSAT_PP
+                };
+                PredOps S0, S1;
+                load(S0, 0, 0);
+                for (int k = 0; k < j; ++k) {
+                    load(S1, k, 1);
+                    comp(S0);
+                    load(S0, min(k + 1, j - 1), 0);            // past the end: the last row again, unused
+                    comp(S1);
                 }
-                mma_blk(acc0, A, B0);
-                mma_blk(acc1, A, B1);
             }
             const f32x16 Lop = ldg(c.ws, c.dT0 + j, lane);
             f32x16 Wa = ksblock<D, KN>(c, j, xa, va) - acc0;
