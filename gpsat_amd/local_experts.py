@@ -391,7 +391,13 @@ class ResultStore:
     def _atomic_write(self, df, name):
         tmp = os.path.join(self.path, f".tmp.r{self.rank}.{os.getpid()}.{name}")
         if name.endswith(".parquet"):
-            df.to_parquet(tmp, engine="pyarrow", index=True)
+            # pyarrow directly, without dictionary encoding and column statistics: a part is written once and read whole, and
+            # the encoder's dictionaries and min / max passes were four fifths of pandas' to_parquet on the preds table
+            # (0.149 -> 0.032 s for 210 k rows; the file is also 13 % smaller)
+            import pyarrow as pa
+            import pyarrow.parquet as pq
+            pq.write_table(pa.Table.from_pandas(df, preserve_index=True), tmp, compression="snappy", use_dictionary=False,
+                           write_statistics=False)
         else:
             df.to_pickle(tmp)
         os.replace(tmp, os.path.join(self.path, name))
@@ -598,6 +604,10 @@ class BatchedLocalExpertOI:
         self.pred_loc = PredictionLocations(coords_col=self.coords_col, **plc)
         from .engine import default_engine
         self.engine = engine if engine is not None else default_engine()
+        self.engine_workers = 2          # engines (HIP streams) that take the chunks of a wave in turn; see run_shard
+        self._extra_engines = []
+        self.pack_threads = 4            # host threads that pack one engine call's arrays
+        self._pack_pool = None
         # tile membership for all experts in one GPU call (bit-identical to the host selector)
         self.device_select = device_select
         self.timings = {}
@@ -687,7 +697,7 @@ class BatchedLocalExpertOI:
             engine_chunk: Optional[int] = None):
         """See the module docstring.  ``store_every``: expert locations per flushed wave (default 4096;
         ``max_tiles_per_call`` is the older name of the same knob).  ``engine_chunk``: tiles per engine call inside a wave
-        (default 2048): while the GPU works on one call the host packs the next (gather, scale, de-mean, centre, cast).  ``rank`` / ``world_size``: tile-sharded run, one
+        (default 4096): while the GPU works on one call the host packs the next (gather, scale, de-mean, centre, cast).  ``rank`` / ``world_size``: tile-sharded run, one
         process per GPU (default: taken from an initialised ``torch.distributed`` group, else 0 / 1); with
         ``gather=True`` rank 0 returns the global tables in expert order, the other ranks their own shard's
         (``gather="always"`` runs the exchange in a group of one rank too).
@@ -714,7 +724,7 @@ class BatchedLocalExpertOI:
         D, H = len(cc), len(cc) + 2
         xl = self.expert_locs
         wave_n = int(store_every or max_tiles_per_call or 4096)
-        chunk_n = max(1, int(engine_chunk or 2048))
+        chunk_n = max(1, int(engine_chunk or 4096))
         # ---- expert_locs table + config bookkeeping (local_experts.py:873-903); rank 0 owns the shared files
         config_id = 1
         if store_path:
@@ -747,6 +757,8 @@ class BatchedLocalExpertOI:
         locs = xl[cc].values.astype(np.float64)[ex]
 
         # ---------------- pass 1: membership, prediction coordinates, parameter vectors (whole-array) ----------------
+        self.timings["setup_s"] = time.perf_counter() - t_start
+        self.timings["flush_wait_s"] = 0.0
         t0 = time.perf_counter()
         refs = xl.iloc[ex]
         if len(self.local_select):
@@ -839,7 +851,7 @@ class BatchedLocalExpertOI:
         obs_all = self.df[self.obs_col].values.astype(np.float64)
         assert not np.isnan(coords_all).any(), "nans found in coords"
         assert not np.isnan(obs_all).any(), "nans found in obs"
-        self.timings.update(pack_wait_s=0.0, engine_s=0.0, tables_s=0.0, flush_s=0.0)
+        self.timings.update(engine_s=0.0, engine_call_s=0.0, kernel_s=0.0, tables_s=0.0, flush_s=0.0)
 
         def tables_for(items, fixed, pred_cat, cov_cat=None):
             return self._tables(ex[items], locs[items], kind[items], n_obs[items], fixed, pred_cat,
@@ -850,28 +862,55 @@ class BatchedLocalExpertOI:
 
         # ---------------- pass 2: waves of one shard ----------------
         def pack_job(ids, pi):
-            """Host-side intake of one engine call (a1 of the reference in fp64): gather the tiles' rows, scale, de-mean."""
+            """Host-side intake of one engine call (a1 of the reference in fp64): gather the tiles' rows, scale, de-mean, centre,
+            cast -- by `pack_threads` threads, each writing its range of tiles into the call's arrays (NumPy releases the GIL
+            in the gathers and the arithmetic)."""
             t_, p_ = tmpl[pi], pinfo[pi]
             Ns = n_obs[ids]
-            rows = np.concatenate([idx[off[i]:off[i + 1]] for i in ids])
-            tile_of_row = np.repeat(np.arange(len(ids)), Ns)
-            X = coords_all[rows] / t_["coords_scale"]         # base_model.py:243
-            yv_ = obs_all[rows]
             o_off = np.concatenate([[0], np.cumsum(Ns)]).astype(np.int64)
-            mean = (np.add.reduceat(yv_, o_off[:-1]) / Ns) if t_["local_mean"] else np.zeros(len(ids))
-            y = (yv_ - mean[tile_of_row]) / t_["obs_scale"]   # base_model.py:244-245
             Ps = n_pred[ids] if predict else np.zeros(len(ids), dtype=np.int64)
             p_off = np.concatenate([[0], np.cumsum(Ps)]).astype(np.int64)
-            Xs = np.concatenate([pcs[i] for i in ids]) if predict else np.zeros((0, D))
-            if p_["apply_scale"]:
-                Xs = Xs / t_["coords_scale"]
-            if self.dtype == "f32":
-                # what the engine does with fp64 host arrays for the fp32 kernels (per-tile centring, then the cast), done
-                # here so that it too overlaps the previous call
-                from .engine import centre_tiles
-                if len(X):
-                    X, Xs = centre_tiles(X, Xs, o_off, p_off)
-                X, y, Xs = (np.ascontiguousarray(v, dtype=np.float32) for v in (X, y, Xs))
+            out_dt = np.float32 if self.dtype == "f32" else np.float64
+            X = np.empty((int(o_off[-1]), D), dtype=out_dt)
+            y = np.empty(int(o_off[-1]), dtype=out_dt)
+            Xs = np.empty((int(p_off[-1]), D), dtype=out_dt)
+            mean = np.zeros(len(ids))
+            consecutive = len(ids) > 0 and bool(np.all(np.diff(ids) == 1))
+
+            def sub(a, b):
+                sl = ids[a:b]
+                if consecutive:
+                    rows = idx[off[sl[0]]:off[sl[-1] + 1]]
+                else:
+                    rows = np.concatenate([idx[off[i]:off[i + 1]] for i in sl])
+                ns, oo = Ns[a:b], o_off[a:b + 1] - o_off[a]
+                Xd = coords_all[rows] / t_["coords_scale"]        # base_model.py:243
+                yv_ = obs_all[rows]
+                if t_["local_mean"]:
+                    mean[a:b] = np.add.reduceat(yv_, oo[:-1]) / ns
+                yd = (yv_ - np.repeat(mean[a:b], ns)) / t_["obs_scale"]   # base_model.py:244-245
+                if predict:
+                    Xsd = np.concatenate([pcs[i] for i in sl]) if b > a else np.zeros((0, D))
+                    if p_["apply_scale"]:
+                        Xsd = Xsd / t_["coords_scale"]
+                else:
+                    Xsd = np.zeros((0, D))
+                if self.dtype == "f32" and len(Xd):
+                    # what the engine does with fp64 host arrays for the fp32 kernels (per-tile centring, then the cast), done
+                    # here so that it too overlaps the previous call
+                    from .engine import centre_tiles
+                    Xd, Xsd = centre_tiles(Xd, Xsd, oo, p_off[a:b + 1] - p_off[a])
+                X[o_off[a]:o_off[b]] = Xd
+                y[o_off[a]:o_off[b]] = yd
+                Xs[p_off[a]:p_off[b]] = Xsd
+
+            nsub = max(1, min(self.pack_threads, len(ids) // 128))
+            bounds = np.linspace(0, len(ids), nsub + 1).astype(np.int64)
+            if nsub == 1:
+                sub(0, len(ids))
+            else:
+                for f_ in [self._sub_pool().submit(sub, int(bounds[j]), int(bounds[j + 1])) for j in range(nsub)]:
+                    f_.result()
             return dict(o_off=o_off, X=X, y=y, p_off=p_off, Xs=Xs, mean=mean)
 
         # ---------------- pass 2: waves of one shard ----------------
@@ -914,15 +953,55 @@ class BatchedLocalExpertOI:
                     pending.pop().result()
                 pending.append(flusher.submit(shard_store.write_wave, tables))
                 self.timings["flush_s"] += time.perf_counter() - tf
+                if len(waves) == 1:
+                    single["tables"] = tables                          # the only wave's tables ARE the shard's tables
                 fixed_rows.append(fixed)
                 pred_rows.append(pred_cat)
                 if want_cov:
                     cov_rows.append(cov_cat)
 
             pending = []
-            with ThreadPoolExecutor(max_workers=1) as pool, ThreadPoolExecutor(max_workers=1) as flusher:
+            single = {}
+            # Engine calls of consecutive chunks are issued from `n_eng` threads, each with an engine (HIP stream, workspace)
+            # of its own: the second call's kernel is queued on the GPU while the first one runs and its workgroups take
+            # over the CUs the first one's tail leaves idle; packing, the copies and the unpacking of one call overlap the
+            # kernel of the other.  `load_params.previous` makes every call depend on the one before: one engine then.
+            engines = self._engine_pool(1 if self.use_previous else self.engine_workers)
+            n_eng = len(engines)
+            import queue
+            free_engines = queue.Queue()
+            for e_ in engines:
+                free_engines.put(e_)
+            pk_f, r_f = {}, {}
+
+            def call_engine(k, th_override=None):
+                wi, pi, loc_ids = jobs[k]
+                ids = waves[wi][loc_ids]
+                pk = pk_f.pop(k).result()
+                t_, p_ = tmpl[pi], pinfo[pi]
+                eng_ = free_engines.get()
                 try:
-                    nxt = pool.submit(pack_job, waves[jobs[0][0]][jobs[0][2]], jobs[0][1]) if jobs else None
+                    te = time.perf_counter()
+                    r = eng_.fit_predict_batch(D=D, obs_off=pk["o_off"], X=pk["X"], y=pk["y"], pred_off=pk["p_off"],
+                                               Xs=pk["Xs"], theta0=theta0[ids] if th_override is None else th_override,
+                                               lo=lo[ids], hi=hi[ids], trainable=t_["trainable"], kernel=p_["kernel"],
+                                               optimiser=p_["optimiser"], max_iter=p_["max_iter"],
+                                               dtype=self.dtype, **p_["eng_kw"],
+                                               **({"full_cov": True} if p_["full_cov"] else {}))
+                    return pk, r, time.perf_counter() - te
+                finally:
+                    free_engines.put(eng_)
+
+            flusher = ThreadPoolExecutor(max_workers=1)
+            with ThreadPoolExecutor(max_workers=max(1, n_eng)) as pack_pool, ThreadPoolExecutor(max_workers=n_eng) as eng_pool:
+                try:
+                    def submit(k):
+                        if k < len(jobs):
+                            pk_f[k] = pack_pool.submit(pack_job, waves[jobs[k][0]][jobs[k][2]], jobs[k][1])
+                            if not self.use_previous:
+                                r_f[k] = eng_pool.submit(call_engine, k)
+                    for k in range(min(len(jobs), n_eng + 1)):
+                        submit(k)
                     done_waves = 0
                     for k, (wi, pi, loc_ids) in enumerate(jobs):
                         while done_waves < wi:                            # waves without a single model tile (stubs, errors only)
@@ -934,32 +1013,26 @@ class BatchedLocalExpertOI:
                             open_wave(wi)
                         fixed, preds, covs = state[wi]
                         ids = waves[wi][loc_ids]
-                        te = time.perf_counter()
-                        pk = nxt.result()
-                        self.timings["pack_wait_s"] += time.perf_counter() - te
-                        if k + 1 < len(jobs):
-                            nxt = pool.submit(pack_job, waves[jobs[k + 1][0]][jobs[k + 1][2]], jobs[k + 1][1])
                         t_, p_ = tmpl[pi], pinfo[pi]
-                        th_call = theta0[ids]
+                        te = time.perf_counter()
                         if self.use_previous:
                             if prev["theta"] is None:
                                 prev["theta"] = t_["theta_default"].copy()
                             th_call = np.tile(prev["theta"], (len(ids), 1))
                             for sl, tol in t_["clamp"]:                   # set_parameters(prev), then the constraints' clamp
                                 th_call[:, sl] = clamp_within(th_call[:, sl], t_["lo"][sl], t_["hi"][sl], tol)
-                        te = time.perf_counter()
-                        r = self.engine.fit_predict_batch(D=D, obs_off=pk["o_off"], X=pk["X"], y=pk["y"], pred_off=pk["p_off"],
-                                                          Xs=pk["Xs"], theta0=th_call, lo=lo[ids], hi=hi[ids],
-                                                          trainable=t_["trainable"], kernel=p_["kernel"],
-                                                          optimiser=p_["optimiser"], max_iter=p_["max_iter"],
-                                                          dtype=self.dtype, **p_["eng_kw"],
-                                                          **({"full_cov": True} if p_["full_cov"] else {}))
-                        if self.use_previous and p_["optimiser"] != "none":
+                            pk, r, call_s = call_engine(k, th_call)
                             for kk in range(len(ids)):                    # expert order; only successful optimisations, no NaN
-                                if r.status[kk] == 0 and save_params[ids[kk]] and not np.isnan(r.theta[kk]).any():
+                                if p_["optimiser"] != "none" and r.status[kk] == 0 and save_params[ids[kk]] \
+                                        and not np.isnan(r.theta[kk]).any():
                                     prev["theta"] = 0.95 * prev["theta"] + 0.05 * r.theta[kk]
-                        dt = (time.perf_counter() - te) / len(ids)
-                        self.timings["engine_s"] += time.perf_counter() - te
+                        else:
+                            pk, r, call_s = r_f.pop(k).result()
+                        submit(k + n_eng + 1)
+                        self.timings["engine_s"] += time.perf_counter() - te     # what the main thread waited for this call
+                        self.timings["engine_call_s"] += call_s                  # the calls themselves (they overlap)
+                        self.timings["kernel_s"] += r.kernel_ms * 1e-3
+                        dt = call_s / len(ids)
                         fixed[loc_ids, :H] = r.theta
                         fixed[loc_ids, H] = r.nll
                         fixed[loc_ids, H + 1] = r.status
@@ -990,51 +1063,91 @@ class BatchedLocalExpertOI:
                             open_wave(done_waves)
                         close_wave(done_waves)
                         done_waves += 1
-                finally:
-                    # the last queued flush (and, after a fault, the one of the last complete wave) is on disk before this
-                    # returns or the fault propagates: a committed wave survives whatever happens to the next one
+                except BaseException:
+                    # after a fault the flush of the last complete wave is on disk before the fault propagates: a committed
+                    # wave survives whatever happens to the next one
                     while pending:
                         pending.pop().result()
+                    flusher.shutdown(wait=True)
+                    raise
+                # the last queued flush goes on while the caller's tables are assembled; run() waits for it before it returns
+                # (the flusher pool's exit below would wait as well: the writer thread is handed over instead)
+                last_flush.extend(pending)
+                flusher_keep.append(flusher)
             fixed_all = np.concatenate(fixed_rows) if fixed_rows else np.zeros((0, H + 6))
             preds_all = np.concatenate(pred_rows) if pred_rows else np.zeros((0, 3))
             cnt = np.where(kind[mine] == 2, n_pred[mine] if predict else 0, 0).astype(np.int64)
             cov_all = (np.concatenate(cov_rows) if cov_rows else np.zeros((0, 2))) if want_cov else None
+            shard_tables.append(single.get("tables"))
             return fixed_all, preds_all, cnt, mine, cov_all
 
-        all_items = np.nonzero(kind != 0)[0]
-        if logical:
-            # every logical shard on this engine, merged by the routine that closes the gather
-            shards = []
-            for r_ in range(world_size):
-                st_r = ResultStore(store_path, rank=r_)
-                st_r.drop_uncommitted()
-                shards.append(run_shard(parts[r_], st_r))
-            fixed_g, preds_g, _ = sharding.assemble_global([sh[:4] for sh in shards], len(ex))
-            cov_g = None
-            if want_cov:
-                cc2 = [np.where(np.array([pinfo[p]["full_cov"] for p in prof_id[sh[3]]], dtype=bool), sh[2] ** 2, 0) for sh in shards]
-                cov_g = sharding.assemble_global([(sh[0], sh[4], c2, sh[3]) for sh, c2 in zip(shards, cc2)], len(ex))[1]
-            out = tables_for(all_items, fixed_g[all_items], preds_g, cov_g)
-        else:
-            mine = parts[rank] if world_size > 1 else parts[0]
-            fixed_all, preds_all, cnt, _, cov_all = run_shard(mine, store)
-            out = None
-            if gather and (world_size > 1 or (gather == "always" and d_world == 1 and _dist_initialised())):
-                # ONE exchange of per-tile results (RCCL over xGMI on the GPU node); tables in expert order on rank 0
-                # (gather="always": also in a group of ONE rank -- the one-GPU rehearsal of the exchange on RCCL)
-                dev_id = getattr(self.engine, "device_id", None)
-                got = sharding.gather_arrays(fixed_all, preds_all, cnt, mine, len(ex), world_size, rank, dev_id)
-                got_c = None
-                if want_cov:                                         # the P x P blocks travel the same way (counts P^2)
-                    c2 = np.where(np.array([pinfo[p]["full_cov"] for p in prof_id[mine]], dtype=bool), cnt ** 2, 0)
-                    got_c = sharding.gather_arrays(fixed_all, cov_all, c2, mine, len(ex), world_size, rank, dev_id)
-                if rank == 0:
-                    fixed_g, preds_g, _ = got
-                    out = tables_for(all_items, fixed_g[all_items], preds_g, got_c[1] if got_c is not None else None)
-            if out is None:
-                out = tables_for(mine, fixed_all, preds_all, cov_all)
+        last_flush, flusher_keep, shard_tables = [], [], []
+
+        def finish_flushes():
+            tf = time.perf_counter()
+            while last_flush:
+                last_flush.pop().result()
+            for fl in flusher_keep:
+                fl.shutdown(wait=True)
+            del flusher_keep[:]
+            self.timings["flush_wait_s"] += time.perf_counter() - tf
+
+        try:
+            all_items = np.nonzero(kind != 0)[0]
+            if logical:
+                # every logical shard on this engine, merged by the routine that closes the gather
+                shards = []
+                for r_ in range(world_size):
+                    st_r = ResultStore(store_path, rank=r_)
+                    st_r.drop_uncommitted()
+                    shards.append(run_shard(parts[r_], st_r))
+                fixed_g, preds_g, _ = sharding.assemble_global([sh[:4] for sh in shards], len(ex))
+                cov_g = None
+                if want_cov:
+                    cc2 = [np.where(np.array([pinfo[p]["full_cov"] for p in prof_id[sh[3]]], dtype=bool), sh[2] ** 2, 0) for sh in shards]
+                    cov_g = sharding.assemble_global([(sh[0], sh[4], c2, sh[3]) for sh, c2 in zip(shards, cc2)], len(ex))[1]
+                out = tables_for(all_items, fixed_g[all_items], preds_g, cov_g)
+            else:
+                mine = parts[rank] if world_size > 1 else parts[0]
+                fixed_all, preds_all, cnt, _, cov_all = run_shard(mine, store)
+                out = None
+                if gather and (world_size > 1 or (gather == "always" and d_world == 1 and _dist_initialised())):
+                    # ONE exchange of per-tile results (RCCL over xGMI on the GPU node); tables in expert order on rank 0
+                    # (gather="always": also in a group of ONE rank -- the one-GPU rehearsal of the exchange on RCCL)
+                    dev_id = getattr(self.engine, "device_id", None)
+                    got = sharding.gather_arrays(fixed_all, preds_all, cnt, mine, len(ex), world_size, rank, dev_id)
+                    got_c = None
+                    if want_cov:                                         # the P x P blocks travel the same way (counts P^2)
+                        c2 = np.where(np.array([pinfo[p]["full_cov"] for p in prof_id[mine]], dtype=bool), cnt ** 2, 0)
+                        got_c = sharding.gather_arrays(fixed_all, cov_all, c2, mine, len(ex), world_size, rank, dev_id)
+                    if rank == 0:
+                        fixed_g, preds_g, _ = got
+                        out = tables_for(all_items, fixed_g[all_items], preds_g, got_c[1] if got_c is not None else None)
+                if out is None:
+                    out = shard_tables[-1] if shard_tables and shard_tables[-1] is not None else tables_for(mine, fixed_all, preds_all, cov_all)
+        finally:
+            finish_flushes()                                       # also after a fault: what was committed is on disk
         self.run_seconds = time.perf_counter() - t_start
+        self.timings["total_s"] = self.run_seconds
         return out
+
+    def _sub_pool(self):
+        if self._pack_pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pack_pool = ThreadPoolExecutor(max_workers=self.pack_threads)
+        return self._pack_pool
+
+    def _engine_pool(self, n):
+        """The engine given to the constructor plus up to n - 1 more on the same device, created on first use and kept (an
+        engine that is not a gpsat_amd Engine -- the CPU tests' stand-ins -- is used alone)."""
+        from .engine import Engine
+        if n > 1 and isinstance(self.engine, Engine):
+            try:
+                while len(self._extra_engines) < n - 1:
+                    self._extra_engines.append(Engine(self.engine.device_id))
+            except Exception as e:                                   # not enough memory for a second workspace, ...
+                warnings.warn(f"only {1 + len(self._extra_engines)} engine(s) for the chunks of a wave: {e}")
+        return [self.engine] + self._extra_engines[:max(0, n - 1)]
 
     # ------------------------------------------------------------------------------------------------------
     def _tables(self, ex_ids, locs, kind, n_obs, fixed, pred_cat, pcs, save_params, devices, optimise, config_id,

@@ -30,13 +30,14 @@ cfg = dict(
     pred_loc_config={"method": "from_dataframe", "df": pred, "max_dist": 1.0 / side})
 eng = Engine(0)
 chunk = int(os.environ.get("CHUNK", 0)) or None             # tiles per engine call (None: the orchestrator's default)
+se = int(os.environ.get("STORE_EVERY", 4096))                # expert locations per flushed wave
 for dev_sel in (True, False):
     with tempfile.TemporaryDirectory() as d:
         oi = BatchedLocalExpertOI(engine=eng, device_select=dev_sel, **cfg)
         if dev_sel:
-            oi.run(store_path=os.path.join(d, "warm"), store_every=4096)      # warm-up (allocations, first launch)
+            oi.run(store_path=os.path.join(d, "warm"), store_every=se, engine_chunk=chunk)      # warm-up (allocations, first launch)
         t0 = time.perf_counter()
-        tabs = oi.run(store_path=os.path.join(d, "s"), store_every=4096, engine_chunk=chunk)
+        tabs = oi.run(store_path=os.path.join(d, "s"), store_every=se, engine_chunk=chunk)
         dt = time.perf_counter() - t0
         rd = tabs["run_details"]
         print(f"device_select={dev_sel}: {len(rd)} experts, mean obs/tile {rd['num_obs'].mean():.0f}, preds {len(tabs['preds'])}, "
