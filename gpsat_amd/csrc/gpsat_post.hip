@@ -7,6 +7,10 @@
 //                   w = prod_d normpdf(pred_d; xprt_d, sigma[row]), out[var][g] = sum w v / sum w.
 // One wave per output element, lanes stride over the inputs (coalesced), fixed-order wave reduction => results are
 // reproducible bit for bit (the reference accumulates sequentially; agreement is to fp64 rounding, ~1e-15 relative).
+// smooth_kernel is bound by fp64 ALU work (two divisions and an exp per pair: 480 G pairs/s), not by its reads (24 B per pair
+// out of L1 / L2): the LDS-tiled form (one thread per output, inputs staged in tiles of 256 and read by broadcast;
+// scripts/experiments/r4_smooth_kernel_lds_tiled.patch) measured 390 G pairs/s at 131 072 locations and 17 instead of 229 at
+// 4 096 (a quarter of the waves in flight, one dependent accumulation chain per thread) -- not adopted.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "gpsat_kernels.h"

@@ -592,13 +592,21 @@ class BatchedLocalExpertOI:
                 pred_kwargs=dict(model_config.get("replacement_pred_kwargs") or {}))
         self.params_to_store = model_config.get("params_to_store") or PARAM_NAMES
         self.load_params = model_config.get("load_params")
-        # load_params.previous (local_experts.py:1059-1064): start every tile from the running average of earlier optima
-        self.use_previous = bool(self.load_params is not None and self.load_params.get("previous", False))
-        if self.use_previous:
-            extra = set(self.load_params) - {"previous"}
-            if extra:
-                raise NotImplementedError(f"load_params.previous=True together with {sorted(extra)}")
+        # load_params.previous (local_experts.py:1059-1064): start every tile from the running average of earlier optima.
+        # What the reference's load_params does with the combinations (local_experts.py:553-609: `if file is not None: ...
+        # elif previous is not None: param_dict = previous_params`):
+        #   file + previous            the FILE's parameters are set, the running average is carried along and never used;
+        #   previous + direct values   the direct values are never applied (previous=True: the running average;
+        #                              previous=False: nothing is set at all);
+        # and `previous` among the keys makes _same_param_table False (:749-758), i.e. parameters are always stored.
+        self.use_previous = False
+        self._lp_keys = set(self.load_params) if self.load_params is not None else set()
+        lp = self.load_params
+        if lp is not None and lp.get("file") is None and lp.get("previous") is not None:
+            self.use_previous = bool(lp["previous"])
             self.load_params = None
+        elif lp is not None and "previous" in lp:
+            self.load_params = {k: v for k, v in lp.items() if k not in ("previous", "previous_params")}
         # ---- prediction locations (local_experts.py:254-264)
         plc = dict(pred_loc_config or {"method": "expert_loc"})
         self.pred_loc = PredictionLocations(coords_col=self.coords_col, **plc)
@@ -819,7 +827,7 @@ class BatchedLocalExpertOI:
                     theta0[m_] = th
                     kind[m_[~got]] = 0                              # nothing loadable: tile skipped (:1099-1101)
                 same = (lp.get("file") == store_path and lp.get("table_suffix", None) == table_suffix and
-                        set(lp) <= {"file", "table_suffix"})                  # _same_param_table, :749-758
+                        self._lp_keys <= {"file", "table_suffix"})           # _same_param_table, :749-758
                 save_params[:] = not (same and not optimise)        # local_experts.py:1090-1097
             else:
                 # parameters given directly (load_params(**param_dict), local_experts.py:553-604)

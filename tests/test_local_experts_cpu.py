@@ -178,10 +178,16 @@ def test_run_tables_layout_resume_and_load_params(tmp_path):
 def test_unsupported_configs_fail_loudly():
     df, X_grid, noise_std = _notebook_data()
     base = _configs(df, X_grid, 0.1, [0.2], noise_std)
-    bad = dict(base)
-    bad["model_config"] = {**base["model_config"], "load_params": {"previous": True, "file": "somewhere"}}
-    with pytest.raises(NotImplementedError):
-        BatchedLocalExpertOI(engine=OracleEngine(), **bad)
+    # load_params.previous together with a file: the reference reads the file and never uses the running average
+    # (`if file is not None ... elif previous is not None`, local_experts.py:553-609)
+    both = dict(base)
+    both["model_config"] = {**base["model_config"], "load_params": {"previous": True, "file": "somewhere", "table_suffix": "_S"}}
+    oi = BatchedLocalExpertOI(engine=OracleEngine(), **both)
+    assert oi.use_previous is False and oi.load_params == {"file": "somewhere", "table_suffix": "_S"} and "previous" in oi._lp_keys
+    # ... and direct values beside `previous` are never applied
+    oi = BatchedLocalExpertOI(engine=OracleEngine(), **{**base, "model_config": {**base["model_config"],
+                                                        "load_params": {"previous": False, "lengthscales": [0.3]}}})
+    assert oi.use_previous is False and oi.load_params is None
     bad = dict(base)
     bad["model_config"] = {**base["model_config"], "oi_model": "GPflowSVGPModel"}
     with pytest.raises(NotImplementedError):
