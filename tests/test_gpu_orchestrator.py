@@ -119,6 +119,22 @@ def _same(a, b):
         pd.testing.assert_frame_equal(da, db, check_exact=True)
 
 
+def test_engine_pool_and_chunking_do_not_change_a_bit(eng, tmp_path):
+    """Two engines (HIP streams) taking the chunks of a wave in turn, four packing threads, chunks of 300 tiles -- launches
+    below and above the CU count, i.e. both builds of the fp32 kernels -- against one engine, one thread, one call per wave:
+    the same tables, bit for bit (run_time aside)."""
+    from gpsat_amd.local_experts import BatchedLocalExpertOI
+    cfg = _grid_problem(n_side=40, m=60_000, seed=5)
+    a = BatchedLocalExpertOI(engine=eng, device_select=True, **cfg)
+    a.engine_workers, a.pack_threads = 1, 1
+    ta = a.run(store_path=str(tmp_path / "a"), store_every=4096)
+    b = BatchedLocalExpertOI(engine=eng, device_select=True, **cfg)
+    assert b.engine_workers == 2 and b.pack_threads == 4
+    tb = b.run(store_path=str(tmp_path / "b"), store_every=700, engine_chunk=300)
+    assert len(b._extra_engines) == 1 and len(ta["run_details"]) == 1600
+    _same(ta, tb)
+
+
 def test_kill_and_resume_4096_experts(eng, tmp_path):
     from gpsat_amd.local_experts import BatchedLocalExpertOI, get_results
     cfg = _grid_problem()
