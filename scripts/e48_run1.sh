@@ -1,15 +1,17 @@
 #!/bin/bash
-# Developer (E48): one GPU-box call -- hazard microbenchmark, then factor-dump comparisons of three diagnostic builds.
+# Developer (EXPERIMENTS.md E48): the GPU-box calls of the root-causing, for the record.  Build the diagnostic variants first:
+#   scripts/build_variant.sh dirty -DGPSAT_DUMP -ffp-contract=on -fslp-vectorize   (+ the macros of scripts/experiments/r4_e48_site_variants.patch)
+# then e.g.   gpurun -- 'bash scripts/e48_run1.sh'
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out/e48
-export TMPDIR=/tmp
 L=$PWD/gpsat_amd/csrc
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 scripts/bench_valu_mfma_hazard.hip -o /tmp/bench_vmh || exit 1
-timeout -k 10 240 /tmp/bench_vmh 20000 > gpurun_out/e48/vmh.txt 2>&1 || { echo "vmh failed/timeout"; tail -3 gpurun_out/e48/vmh.txt; exit 1; }
-echo "vmh done"; tail -4 gpurun_out/e48/vmh.txt
-GPSAT_LIB=$L/libgpsat_hip_dirty.so timeout -k 10 400 python3 scripts/e48_dump_compare.py 5 4096 500 > gpurun_out/e48/dump_dirty.txt 2>&1 || { echo "dirty failed"; tail -5 gpurun_out/e48/dump_dirty.txt; exit 1; }
-echo "dirty done"; tail -12 gpurun_out/e48/dump_dirty.txt
-GPSAT_LIB=$L/libgpsat_hip_pad.so E48_SHOW=30 timeout -k 10 500 python3 scripts/e48_dump_compare.py 100 4096 500 > gpurun_out/e48/dump_pad.txt 2>&1 || { echo "pad failed"; tail -5 gpurun_out/e48/dump_pad.txt; exit 1; }
-echo "pad done"; grep -v "differs 0, whose objective differs 0" gpurun_out/e48/dump_pad.txt | tail -30
-GPSAT_LIB=$L/libgpsat_hip_shipdump.so timeout -k 10 300 python3 scripts/e48_dump_compare.py 30 4096 500 > gpurun_out/e48/dump_ship.txt 2>&1 || { echo "ship failed"; tail -5 gpurun_out/e48/dump_ship.txt; exit 1; }
-echo "ship done"; grep -v "differs 0, whose objective differs 0" gpurun_out/e48/dump_ship.txt | tail -8
+for b in bench_valu_mfma_hazard bench_sc1_handoff bench_chain_beside_bf16 bench_pkfma_waw; do
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -Wno-unused-result scripts/$b.hip -o /tmp/$b || exit 1
+  timeout -k 10 400 /tmp/$b > gpurun_out/e48/$b.txt 2>&1 || { echo "$b failed"; exit 1; }
+  tail -3 gpurun_out/e48/$b.txt
+done
+for v in ${VARIANTS:-dirty}; do
+  [ -f $L/libgpsat_hip_$v.so ] || continue
+  GPSAT_LIB=$L/libgpsat_hip_$v.so E48_SHOW=8 E48_SAVE=${SAVE:-0} timeout -k 10 500 python3 scripts/e48_dump_compare.py ${LAUNCHES:-12} 4096 500 > gpurun_out/e48/dump_$v.txt 2>&1 || { echo "$v failed"; exit 1; }
+  echo "== $v: $(grep '^launch' gpurun_out/e48/dump_$v.txt | awk '{print $7}' | tr -d ',' | tr '\n' ' ')"
+done
