@@ -136,7 +136,7 @@ __device__ __forceinline__ float rnd(unsigned& s) { return (float)((int)(lcg(s) 
 // wrong value equals the sum WITHOUT the last term
 template <int VAR>
 __global__ void __launch_bounds__(256, 2) k(const float* __restrict__ big, unsigned long long* out, int* census, int iters, int force_kind,
-                                            int prio, float* sink) {
+                                            int prio, float* sink, int noise) {
     __shared__ int kind_s;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, gw = blockIdx.x * 4 + w, h = lane >> 5;
     if (threadIdx.x == 0) {
@@ -145,7 +145,34 @@ __global__ void __launch_bounds__(256, 2) k(const float* __restrict__ big, unsig
         kind_s = force_kind >= 0 ? force_kind : (atomicAdd(&census[cu], 1) & 1);
     }
     for (int i = threadIdx.x; i < 4096; i += 256) lds_f[i] = 0.25f + 0.001f * (float)(i % 97);
+    if (threadIdx.x < 8) lds_f[17000 + threadIdx.x] = 0.f;
+    if (threadIdx.x == 0) lds_f[18000] = 0.f;
     __syncthreads();
+    if (kind_s == 0 && noise && w > 0) {
+        // sibling waves of the chain wave in the real kernel: LDS block writes / reads (parked k-loops, factor copies), flag
+        // polling with s_sleep, fp32 MFMAs, workspace loads and stores -- until wave 0 of the workgroup is done
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f32x16 acc;
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(big), 0, 0x7fffffff, 0x00020000);
+        f4* area = reinterpret_cast<f4*>(lds_f + 8192 + 2048 * (w - 1));
+        volatile float* stop = lds_f + 18000;
+        float v = 1.0f + lane;
+        for (int round = 0; round < (1 << 22); ++round) {
+            if (*stop != 0.f) break;
+            const f4 x = {v, v + 1.f, v + 2.f, v + 3.f};
+            area[lane] = x; area[64 + lane] = x; area[128 + lane] = x; area[192 + lane] = x;
+            const f4 a = area[(lane + 7) & 63], b = area[64 + ((lane + 13) & 63)];
+            v = a[0] + b[1];
+            for (int spin = 0; spin < 3; ++spin) { if (lds_f[17000 + w] > 1e30f) break; __builtin_amdgcn_s_sleep(2); }
+            for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v, 0.5f, acc, 0, 0, 0);
+            const int so = (int)(((unsigned)(round * 7919 + gw * 104729)) % 60000u) * 4096;
+            u32x4 l0 = __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, so, 16), l1 = __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16 + 1024, so, 16);
+            v += __uint_as_float(l0[0]) * 1e-30f + __uint_as_float(l1[1]) * 1e-30f;
+        }
+        sink[(size_t)gw * 64 + lane] = v + acc[3];
+        return;
+    }
     if (kind_s == 0) {
         unsigned s = 0x9e3779b9u * (gw * 64 + lane + 1), su = 0x7f4a7c15u * (gw + 1);      // su: wave-uniform
         unsigned long long bad1 = 0, bad0 = 0, lost = 0;
@@ -188,6 +215,7 @@ __global__ void __launch_bounds__(256, 2) k(const float* __restrict__ big, unsig
         atomicAdd(&out[8], (unsigned long long)iters);
         atomicAdd(&out[9], lost);
         sink[(size_t)gw * 64 + lane] = keep;
+        if (noise && lane == 0) lds_f[18000] = 1.f;
     } else {
         // partner: bf16 MFMA stream with VALU work (perm / and / sub: the plane split) and loads in between
         f32x16 acc[2];
@@ -220,13 +248,13 @@ __global__ void __launch_bounds__(256, 2) k(const float* __restrict__ big, unsig
 }
 
 template <int VAR>
-static void run(const char* name, const float* big, unsigned long long* out, int* census, int iters, float* sink) {
+static void run(const char* name, const float* big, unsigned long long* out, int* census, int iters, float* sink, int noise = 0) {
     const char* modes[4] = {"beside bf16 partner, prio 3", "beside bf16 partner, prio 0", "victims only, prio 3", "victims only, prio 0"};
     for (int mode = 0; mode < 4; ++mode) {
         (void)hipMemset(census, 0, 4096 * 4);
         (void)hipMemset(out, 0, 128);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k<VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
-        hipLaunchKernelGGL(k<VAR>, dim3(512), dim3(256), 72 * 1024, 0, big, out, census, iters, mode >= 2 ? 0 : -1, (mode & 1) ? 0 : 1, sink);
+        hipLaunchKernelGGL(k<VAR>, dim3(512), dim3(256), 72 * 1024, 0, big, out, census, iters, mode >= 2 ? 0 : -1, (mode & 1) ? 0 : 1, sink, noise);
         hipError_t e = hipDeviceSynchronize();
         unsigned long long h[16];
         (void)hipMemcpy(h, out, 128, hipMemcpyDeviceToHost);
@@ -246,6 +274,7 @@ int main(int argc, char** argv) {
     (void)hipMalloc(&sink, (size_t)512 * 4 * 64 * 4);
     (void)hipMalloc(&out, 128);
     (void)hipMalloc(&census, 4096 * 4);
+    run<7>("register roles, sibling waves make LDS/MFMA/VMEM noise", big, out, census, iters * 4, sink, 1);
     run<7>("loop head with the kernel's register roles", big, out, census, iters, sink);
     run<5>("whole loop head: 3 MFMAs in flight + 8 FMA pairs", big, out, census, iters, sink);
     run<6>("the same, s_nop 3 behind the last packed FMA", big, out, census, iters, sink);
