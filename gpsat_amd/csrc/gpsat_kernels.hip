@@ -671,7 +671,7 @@ __device__ __forceinline__ void pt_group_kloop(const Ctx<D, KN>& c, const Panel<
 #pragma unroll
     for (int n = 0; n < 4; ++n) W[n] = zero16();
     // Exact three-plane bf16 products (see mma_half / kinv_comp): half blocks of 16 k-rows per step, the halves of the next
-    // step in flight, two operand sets in ping-pong (no register copies), 24 v_mfma_f32_32x32x16_bf16 per half step where
+    // steps in flight, operand sets in rotation (no register copies), 24 v_mfma_f32_32x32x16_bf16 per half step where
     // the fp32 pipe took 32 v_mfma_f32_32x32x2_f32 of twice the length (round 4: configs[1] 55.5 -> 61 % of the fp32 peak,
     // parity bounds unchanged).  The rows of a block column arrive in order, so a loop may start before its panel's chain is done.
     if (kmin < j0) {
@@ -682,14 +682,25 @@ __device__ __forceinline__ void pt_group_kloop(const Ctx<D, KN>& c, const Panel<
             S.B0 = ldg_half(c.ws, (k >= ks0) ? k * NB + c0 : c.zb, m, lane);
             S.B1 = ldg_half(c.ws, (k >= ks1) ? k * NB + c1 : c.zb, m, lane);
         };
-        KinvOps S0, S1;
-        load(S0, kmin, 0);
-        for (int k = kmin; k < j0; ++k) {
-            load(S1, k, 1);
+        // three operand sets in rotation: the halves of the next TWO half steps are in flight; past the end the last half
+        // again, unused (n >= 2 here).  One workgroup alone on a CU spends 1 900-2 700 cycles per half step against ~1 000 of
+        // MFMA and split work; with two per CU the other one fills most of that (E57: configs[2] +1.8 %, configs[1] +0.2 %)
+        const int n = 2 * (j0 - kmin);
+        auto load_i = [&](KinvOps& S, int i) { const int ii = min(i, n - 1); load(S, kmin + (ii >> 1), ii & 1); };
+        KinvOps S0, S1, S2;
+        load_i(S0, 0);
+        load_i(S1, 1);
+        int i = 0;
+        for (; i + 3 <= n; i += 3) {
+            load_i(S2, i + 2);
             kinv_comp<false>(W, S0);
-            load(S0, min(k + 1, j0 - 1), 0);          // past the end: the last row again, unused
+            load_i(S0, i + 3);
             kinv_comp<false>(W, S1);
+            load_i(S1, i + 4);
+            kinv_comp<false>(W, S2);
         }
+        if (i < n) { kinv_comp<false>(W, S0); ++i; }
+        if (i < n) kinv_comp<false>(W, S1);
     }
     // U-type: W = K - acc ; M-type: W = -acc
     if (v0 && u0) {
@@ -857,14 +868,23 @@ __device__ __forceinline__ void chain_kloop(const Ctx<D, KN>& c, const Panel<D>&
             tp1 = fmaf(__uint_as_float(a1.q[q >> 2][q & 3]), zk, tp1);
         }
     };
-    RawHalf x0, x1, y0, y1;
-    load(x0, x1, kb, 0);
-    for (int k = kb; k < ke; ++k) {
-        load(y0, y1, k, 1);
-        comp(x0, x1, k, 0);
-        load(x0, x1, min(k + 1, ke - 1), 0);          // past the end: the last row again, unused
-        comp(y0, y1, k, 1);
+    // four operand sets in rotation: three half steps of loads in flight (two half blocks each)
+    const int n = 2 * (ke - kb);
+    RawHalf a0[4], a1[4];
+    // past the end: the last half again, unused (an empty range reads row kb, which exists)
+    auto load_i = [&](int slot, int i) { const int ii = max(min(i, n - 1), 0); load(a0[slot], a1[slot], kb + (ii >> 1), ii & 1); };
+    load_i(0, 0); load_i(1, 1); load_i(2, 2);
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            load_i((u + 3) & 3, i + u + 3);
+            comp(a0[u], a1[u], kb + ((i + u) >> 1), (i + u) & 1);
+        }
     }
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+        if (i + u < n) comp(a0[u], a1[u], kb + ((i + u) >> 1), (i + u) & 1);
 }
 
 // The diagonal chain of panel p (one wave): D00/D01/D11 accumulation over k < j0, the two 32x32
