@@ -659,7 +659,7 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c, const bool want_m) {
         if (TEAM) t0 = __builtin_amdgcn_s_memtime();
         // ---- (A) diagonal region: D_rr' = K_jr,jr' - sum_{k<j0} U_k,jr^T U_k,jr'  and  t_r = sum_{k<j0} U_k,jr^T z_k
         constexpr bool LA = !TEAM;                         // look-ahead of the next panel's diagonal region (la_items)
-        if (LA && c.tid == 0) { sh->gnext[0] = (j0 + PR < NB) ? 0 : 10; sh->g0done = 0; sh->gnext[1] = 0; }
+        if (LA && c.tid == 0) { sh->gnext[0] = (j0 + PR < NB) ? 0 : 10; sh->g0done = 0; sh->gnext[1] = 0; sh->hp[0] = 0; }
         for (int bb = c.vw; bb < 10; bb += c.nwt) {
             int r, r2;
             diag_item(bb, r, r2);
@@ -703,13 +703,32 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c, const bool want_m) {
         // the U columns, the column pairs of the inverse (longest first)
         const int nT = want_m ? 1 : 0;
         const int nU = (NB - j0 - nr + PCW - 1) / PCW;
-        const int nM = want_m ? j0 / 2 : 0;
         auto queue_item = [&](const int idx) {
             if (idx < nT) { trtri_triangle<D, KN, TEAM>(c, j0, nr); PROF_END(c, 6); }
-            else if (idx < nT + nU) { cols_item<D, KN, TEAM, PCW>(c, j0, nr, j0 + nr + PCW * (idx - nT), c.L.Pn); PROF_END(c, 5); }
-            else { trtri_pair<D, KN, TEAM>(c, j0, nr, idx - nT - nU); PROF_END(c, 7); }
+            else { cols_item<D, KN, TEAM, PCW>(c, j0, nr, j0 + nr + PCW * (idx - nT), c.L.Pn); PROF_END(c, 5); }
         };
-        if (LA && w != 0) { la_items<D, KN>(c, j0, j0 + PR, true); PROF_END(c, 3); }
+        // The column pairs of the inverse are DEFERRED by one panel: the pairs of panel j0 - PR (everything they read has been in
+        // memory since that panel's serial part; a pair only feeds the same pair of the next panel and the gradient phase) are
+        // pulled from their own queue (sh->hp[0]) by the waves that would otherwise wait for wave 0's serial part (B) of THIS
+        // panel -- 15 % of an evaluation of an N = 500 tile, after the look-ahead items had run out -- and what is left of them
+        // closes the column phase.  The pairs of the last panel run after the loop.  Same arithmetic per pair and the same order
+        // of a column's alpha terms (panel by panel): bit-identical results.
+        auto deferred_pairs = [&](const int i0p, const int nrp, const bool until_b_done) {
+            for (;;) {
+                if (until_b_done && __hip_atomic_load(&sh->g0done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                int v = 0;
+                if (lane == 0) v = atomicAdd(&sh->hp[0], 1);
+                const int idx = __builtin_amdgcn_readfirstlane(v);
+                if (2 * idx >= i0p) break;
+                trtri_pair<D, KN, TEAM>(c, i0p, nrp, idx);            // ascending: longest k-loop first
+                PROF_END(c, 7);
+            }
+        };
+        if (LA && w != 0) {
+            la_items<D, KN>(c, j0, j0 + PR, true);
+            PROF_END(c, 3);
+            if (want_m && j0 > 0) deferred_pairs(j0 - PR, PR, true);
+        }
         if (w == 0 && c.member == 0) {
             // the serial part: this wave's VALU chain shares its SIMD with a wave of the CU's other workgroup, whose MFMAs
             // (64 cycles each, nothing else issues meanwhile) slip into every dependence gap -- measured 23 cycles per
@@ -812,15 +831,29 @@ __device__ __forceinline__ void phase_potrf(Ctx<D, KN>& c, const bool want_m) {
                 int v = 0;
                 if (lane == 0) v = atomicAdd(&sh->gnext[1], 1);
                 const int idx = __builtin_amdgcn_readfirstlane(v);
-                if (idx >= nT + nU + nM) break;
+                if (idx >= nT + nU) break;
                 queue_item(idx);
             }
+            if (want_m && j0 > 0) deferred_pairs(j0 - PR, PR, false);
         }
         if (LA) la_items<D, KN>(c, j0, j0 + PR, false);
         PROF_END(c, 8);
         team_barrier<TEAM>(c);
         PROF_END(c, 9);
         if (TEAM) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tC += t1 - t0; t0 = t1; }
+    }
+    if (!TEAM && want_m && !sh->fail) {              // the deferred pairs of the last panel (every wave; sh->fail is uniform here)
+        const int j0l = ((NB - 1) / PR) * PR;
+        if (c.tid == 0) sh->hp[0] = 0;
+        __syncthreads();
+        for (;;) {
+            int v = 0;
+            if (lane == 0) v = atomicAdd(&sh->hp[0], 1);
+            const int idx = __builtin_amdgcn_readfirstlane(v);
+            if (2 * idx >= j0l) break;
+            trtri_pair<D, KN, TEAM>(c, j0l, NB - j0l, idx);
+            PROF_END(c, 7);
+        }
     }
     if (TEAM && c.tid == 0 && c.member == 0) {       // developer: 100 MHz ticks of the owner's thread 0 per part (GPSAT_DEBUG_TEAM_STATS)
         __hip_atomic_fetch_add(&c.tc->pad1[0], (int)tW, RLX_AGENT);

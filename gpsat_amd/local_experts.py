@@ -266,16 +266,55 @@ class PredictionLocations:
         return out
 
     def batch(self, locs: np.ndarray, engine=None):
-        """All experts at once: (list of (P_i, D) arrays).  With an engine the ``max_dist`` filter of ``from_dataframe``
-        runs as ONE ``gpsat_select_batch`` call (strict ball, bit-identical membership)."""
+        """All experts at once: a ``RaggedRows`` (``[i]`` is expert i's (P_i, D) array).  With an engine the ``max_dist``
+        filter of ``from_dataframe`` runs as ONE ``gpsat_select_batch`` call (strict ball, bit-identical membership) and the
+        coordinates are gathered in one piece (a Python-level gather per expert cost 4 us x 16 384 experts = 0.07 s)."""
+        D = len(self.coords_col)
         if self.method == "from_dataframe" and engine is not None and self.max_dist is not None and self._sel is None \
                 and 1 <= len(self.found) <= 3:
             frame = pd.DataFrame(self.vals, columns=self.found)
             ds = DeviceSelector(frame, [{"col": list(self.found), "comp": "<", "val": self.max_dist}], engine,
                                 strict_ball=True)
             off, idx = ds.select(pd.DataFrame(locs[:, self.fc_loc], columns=self.found))
-            return [self._rows(idx[off[i]:off[i + 1]], locs[i]) for i in range(len(locs))]
-        return [self(locs[i]) for i in range(len(locs))]
+            cat = np.empty((len(idx), D))
+            cat[:, self.fc_loc] = self.vals[idx]
+            if self.missing:
+                cat[:, self.missing] = np.repeat(locs[:, self.missing], np.diff(off), axis=0)
+            return RaggedRows(cat, off)
+        rows = [self(locs[i]) for i in range(len(locs))]
+        off = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+        return RaggedRows(np.concatenate(rows) if len(rows) else np.zeros((0, D)), off)
+
+
+class RaggedRows:
+    """Row blocks of unequal length kept back to back: ``cat`` (sum P_i, D) and ``off`` (T + 1).  Reads like a list of
+    arrays; ``take`` gathers the blocks of many items without a Python loop."""
+
+    def __init__(self, cat: np.ndarray, off: np.ndarray):
+        self.cat, self.off = cat, np.asarray(off, dtype=np.int64)
+        self.counts = np.diff(self.off)
+
+    def __len__(self):
+        return len(self.off) - 1
+
+    def __getitem__(self, i):
+        return self.cat[self.off[i]:self.off[i + 1]]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def take(self, items) -> np.ndarray:
+        """The blocks of ``items`` (positions, any order) back to back."""
+        items = np.asarray(items, dtype=np.int64)
+        if len(items) == 0:
+            return self.cat[:0]
+        if bool(np.all(np.diff(items) == 1)):
+            return self.cat[self.off[items[0]]:self.off[items[-1] + 1]]
+        cnt = self.counts[items]
+        tot = int(cnt.sum())
+        start = np.concatenate([[0], np.cumsum(cnt)])[:-1]
+        rows = np.arange(tot) - np.repeat(start, cnt) + np.repeat(self.off[items], cnt)
+        return self.cat[rows]
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -301,7 +340,17 @@ def _index_for_repeated(coords_col, loc_rows: np.ndarray, counts):
     return pd.MultiIndex(levels=levels, codes=codes, names=coords_col, verify_integrity=False)
 
 
-_PART_RE = re.compile(r"^(?P<table>[^.].*)\.w(?P<k>\d{6})\.r(?P<r>\d{3})\.(?P<ext>parquet|pkl)$")
+_PART_RE = re.compile(r"^(?P<table>[^.].*)\.w(?P<k>\d{6})\.r(?P<r>\d{3})(\.p(?P<piece>\d{2}))?\.(?P<ext>parquet|pkl)$")
+_PIECE_ROWS = 65536            # a table of a wave longer than this is written as up to _PIECE_MAX row pieces, in parallel
+_PIECE_MAX = 4
+_writers = []
+
+
+def _writer_pool():
+    if not _writers:
+        from concurrent.futures import ThreadPoolExecutor
+        _writers.append(ThreadPoolExecutor(max_workers=_PIECE_MAX))
+    return _writers[0]
 _MARK_RE = re.compile(r"^_wave\.w(?P<k>\d{6})\.r(?P<r>\d{3})\.ok$")
 _WHOLE_RE = re.compile(r"^(?P<table>[^.].*)\.(?P<ext>parquet|pkl)$")
 
@@ -328,7 +377,9 @@ class ResultStore:
     and the fallback when pyarrow is absent; stores written by earlier versions stay readable).  HDF5 / pytables, the
     reference's container, is not a dependency of this backend (``export_hdf5`` converts when pytables is installed).
 
-    Append-only: every flush (``write_wave``) adds ONE new part file per table, ``<table>.w<k>.r<rank>.<ext>``, and
+    Append-only: every flush (``write_wave``) adds ONE new part per table, ``<table>.w<k>.r<rank>.<ext>`` -- a long table
+    (the predictions of a wave) as up to four row pieces ``<table>.w<k>.r<rank>.p<j>.<ext>`` written by as many threads
+    (pyarrow releases the GIL; the parquet writer itself is single-threaded) and read back in order -- and
     commits the wave by writing the marker ``_wave.w<k>.r<rank>.ok`` last (files are written to a temporary name and
     renamed, so a part is either complete or absent).  Parts without their marker -- a run killed mid-flush -- are
     ignored by readers and removed by the next run.  Nothing already written is ever re-read or re-written by an
@@ -425,8 +476,20 @@ class ResultStore:
             return
         _, marks = self._scan()
         k = 1 + max([kk for kk, r in marks if r == self.rank], default=0)
+        jobs = []
         for name, df in tables.items():
-            self._atomic_write(df, f"{name}.w{k:06d}.r{self.rank:03d}.{self.ext}")
+            stem = f"{name}.w{k:06d}.r{self.rank:03d}"
+            npiece = min(_PIECE_MAX, -(-len(df) // _PIECE_ROWS)) if self.fmt == "parquet" else 1
+            if npiece <= 1:
+                jobs.append((df, f"{stem}.{self.ext}"))
+            else:
+                cut = np.linspace(0, len(df), npiece + 1).astype(np.int64)
+                jobs += [(df.iloc[cut[j]:cut[j + 1]], f"{stem}.p{j:02d}.{self.ext}") for j in range(npiece)]
+        if len(jobs) == 1:
+            self._atomic_write(*jobs[0])
+        else:
+            for f_ in [_writer_pool().submit(self._atomic_write, d_, n_) for d_, n_ in jobs]:
+                f_.result()
         mark = os.path.join(self.path, f"_wave.w{k:06d}.r{self.rank:03d}.ok")
         with open(mark + ".tmp", "w") as f:
             f.write(json.dumps({"tables": sorted(tables), "rows": {n: int(len(d)) for n, d in tables.items()}}))
@@ -719,7 +782,9 @@ class BatchedLocalExpertOI:
             engine_chunk: Optional[int] = None):
         """See the module docstring.  ``store_every``: expert locations per flushed wave (default 4096;
         ``max_tiles_per_call`` is the older name of the same knob).  ``engine_chunk``: tiles per engine call inside a wave
-        (default 4096): while the GPU works on one call the host packs the next (gather, scale, de-mean, centre, cast).  ``rank`` / ``world_size``: tile-sharded run, one
+        (default 1024: with two engines the kernel of one call runs while the other call's arrays are copied and unpacked, and the
+        tail of one kernel is filled by the next -- 4096 experts 18.0 -> 19.3 k tiles/s, 16 384 experts 19.5 -> 22.2 k against calls of
+        4096): while the GPU works on one call the host packs the next (gather, scale, de-mean, centre, cast).  ``rank`` / ``world_size``: tile-sharded run, one
         process per GPU (default: taken from an initialised ``torch.distributed`` group, else 0 / 1); with
         ``gather=True`` rank 0 returns the global tables in expert order, the other ranks their own shard's
         (``gather="always"`` runs the exchange in a group of one rank too).
@@ -746,7 +811,7 @@ class BatchedLocalExpertOI:
         D, H = len(cc), len(cc) + 2
         xl = self.expert_locs
         wave_n = int(store_every or max_tiles_per_call or 4096)
-        chunk_n = max(1, int(engine_chunk or 4096))
+        chunk_n = max(1, int(engine_chunk or 1024))
         # ---- expert_locs table + config bookkeeping (local_experts.py:873-903); rank 0 owns the shared files
         config_id = 1
         if store_path:
@@ -801,8 +866,9 @@ class BatchedLocalExpertOI:
             pcs = pcs_f.result()
             sel_pool.shutdown(wait=True)
         else:
-            pcs = self.pred_loc.batch(locs, self.engine if self.device_select else None) if len(ex) else []
-        n_pred = np.array([len(p) for p in pcs], dtype=np.int64)
+            pcs = self.pred_loc.batch(locs, self.engine if self.device_select else None) if len(ex) \
+                else RaggedRows(np.zeros((0, D)), np.zeros(1, dtype=np.int64))
+        n_pred = pcs.counts.astype(np.int64)
         self.timings["select_s"] = time.perf_counter() - t0
         t0 = time.perf_counter()
         # item kinds: 0 skipped silently (no prediction locations, local_experts.py:962-965), 1 stub row
@@ -885,10 +951,11 @@ class BatchedLocalExpertOI:
         assert not np.isnan(coords_all).any(), "nans found in coords"
         assert not np.isnan(obs_all).any(), "nans found in obs"
         self.timings.update(engine_s=0.0, engine_call_s=0.0, kernel_s=0.0, tables_s=0.0, flush_s=0.0)
+        self.timings["calls"] = []          # per engine call: (job, tiles, start, end, kernel seconds), times from the start of run()
 
         def tables_for(items, fixed, pred_cat, cov_cat=None):
             return self._tables(ex[items], locs[items], kind[items], n_obs[items], fixed, pred_cat,
-                                [pcs[i] for i in items] if predict else None, save_params[items],
+                                (pcs, items) if predict else None, save_params[items],
                                 [tmpl[p]["device"] for p in prof_id[items]], optimise, config_id, table_suffix,
                                 cov_cat=cov_cat, cov_tiles=(kind[items] == 2) & np.array([pinfo[p]["full_cov"] for p in prof_id[items]], dtype=bool)
                                 if want_cov else None)
@@ -923,7 +990,7 @@ class BatchedLocalExpertOI:
                     mean[a:b] = np.add.reduceat(yv_, oo[:-1]) / ns
                 yd = (yv_ - np.repeat(mean[a:b], ns)) / t_["obs_scale"]   # base_model.py:244-245
                 if predict:
-                    Xsd = np.concatenate([pcs[i] for i in sl]) if b > a else np.zeros((0, D))
+                    Xsd = pcs.take(sl)
                     if p_["apply_scale"]:
                         Xsd = Xsd / t_["coords_scale"]
                 else:
@@ -1021,7 +1088,9 @@ class BatchedLocalExpertOI:
                                                optimiser=p_["optimiser"], max_iter=p_["max_iter"],
                                                dtype=self.dtype, **p_["eng_kw"],
                                                **({"full_cov": True} if p_["full_cov"] else {}))
-                    return pk, r, time.perf_counter() - te
+                    t1 = time.perf_counter()
+                    self.timings["calls"].append((k, len(ids), round(te - t_start, 4), round(t1 - t_start, 4), round(r.kernel_ms * 1e-3, 4)))
+                    return pk, r, t1 - te
                 finally:
                     free_engines.put(eng_)
 
@@ -1209,10 +1278,12 @@ class BatchedLocalExpertOI:
             out[pn] = pd.DataFrame({"_dim_0": np.tile(np.arange(width), int(sp.sum())), pn: vals},
                                    index=_index_for_repeated(cc, locs[sp], np.full(int(sp.sum()), width)))
         if pcs is not None:
-            cnt = np.array([len(p) if t else 0 for p, t in zip(pcs, tile)], dtype=np.int64)
+            rag, items = pcs                                       # the run's prediction coordinates and these items' positions
+            items = np.asarray(items, dtype=np.int64)
+            cnt = np.where(tile, rag.counts[items], 0).astype(np.int64)
             tot = int(cnt.sum())
             assert tot == len(pred_cat), (tot, len(pred_cat))
-            raw = np.concatenate([p for p, t in zip(pcs, tile) if t]) if tot else np.zeros((0, D))
+            raw = rag.take(items[tile]) if tot else np.zeros((0, D))
             dim0 = np.arange(tot) - np.repeat(np.concatenate([[0], np.cumsum(cnt)])[:-1], cnt)
             pr = {"_dim_0": dim0, "f*": pred_cat[:, 0], "f*_var": pred_cat[:, 1], "y_var": pred_cat[:, 2],
                   "f_bar": np.repeat(fixed[:, H + 5], cnt)}

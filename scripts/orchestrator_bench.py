@@ -31,9 +31,11 @@ cfg = dict(
 eng = Engine(0)
 chunk = int(os.environ.get("CHUNK", 0)) or None             # tiles per engine call (None: the orchestrator's default)
 se = int(os.environ.get("STORE_EVERY", 4096))                # expert locations per flushed wave
-for dev_sel in (True, False):
+for dev_sel in ((True,) if os.environ.get("DEVICE_ONLY") else (True, False)):
     with tempfile.TemporaryDirectory() as d:
         oi = BatchedLocalExpertOI(engine=eng, device_select=dev_sel, **cfg)
+        if os.environ.get("ENGINES"):
+            oi.engine_workers = int(os.environ["ENGINES"])
         if dev_sel:
             oi.run(store_path=os.path.join(d, "warm"), store_every=se, engine_chunk=chunk)      # warm-up (allocations, first launch)
         t0 = time.perf_counter()
@@ -41,4 +43,5 @@ for dev_sel in (True, False):
         dt = time.perf_counter() - t0
         rd = tabs["run_details"]
         print(f"device_select={dev_sel}: {len(rd)} experts, mean obs/tile {rd['num_obs'].mean():.0f}, preds {len(tabs['preds'])}, "
-              f"{dt:.3f} s end to end -> {len(rd) / dt:.0f} tiles/s; split (s): " + ", ".join(f"{k} {v:.3f}" for k, v in oi.timings.items()))
+              f"{dt:.3f} s end to end -> {len(rd) / dt:.0f} tiles/s; split (s): " + ", ".join(f"{k} {v:.3f}" for k, v in oi.timings.items() if k != "calls")
+              + f"; calls (job, tiles, start, end, kernel s): {oi.timings['calls']}")
