@@ -397,6 +397,7 @@ class ResultStore:
             raise ImportError("fmt='parquet' needs pyarrow")
         self.fmt = fmt
         self.ext = "parquet" if fmt == "parquet" else "pkl"
+        self._open_k = None
         if path:
             os.makedirs(path, exist_ok=True)
 
@@ -467,17 +468,36 @@ class ResultStore:
             df.to_pickle(tmp)
         os.replace(tmp, os.path.join(self.path, name))
 
-    def write_wave(self, tables: Dict[str, pd.DataFrame]):
-        """One committed part per non-empty table."""
+    def _wave_number(self):
+        """The number of the wave being written (fixed by its first piece or, without pieces, by ``write_wave``)."""
+        if self._open_k is None:
+            _, marks = self._scan()
+            self._open_k = 1 + max([kk for kk, r in marks if r == self.rank], default=0)
+        return self._open_k
+
+    def write_piece(self, name: str, j: int, df: pd.DataFrame):
+        """Row piece ``j`` (0, 1, ...; in row order) of table ``name`` of the wave that the next ``write_wave`` commits: the
+        rows of a long table that are ready before the wave is (the predictions of an engine call), written while the wave
+        still runs.  Uncommitted like any part until the marker is there."""
+        if not self.path or df is None or not len(df):
+            return
+        assert 0 <= j < 100
+        self._atomic_write(df, f"{name}.w{self._wave_number():06d}.r{self.rank:03d}.p{j:02d}.{self.ext}")
+
+    def write_wave(self, tables: Dict[str, pd.DataFrame], prewritten=()):
+        """One committed part per non-empty table (``prewritten``: tables whose rows went out as ``write_piece`` pieces)."""
         if not self.path:
             return
         tables = {k: v for k, v in tables.items() if v is not None and len(v)}
         if not tables:
+            self._open_k = None
             return
-        _, marks = self._scan()
-        k = 1 + max([kk for kk, r in marks if r == self.rank], default=0)
+        k = self._wave_number()
+        self._open_k = None
         jobs = []
         for name, df in tables.items():
+            if name in prewritten:
+                continue
             stem = f"{name}.w{k:06d}.r{self.rank:03d}"
             npiece = min(_PIECE_MAX, -(-len(df) // _PIECE_ROWS)) if self.fmt == "parquet" else 1
             if npiece <= 1:
@@ -487,7 +507,7 @@ class ResultStore:
                 jobs += [(df.iloc[cut[j]:cut[j + 1]], f"{stem}.p{j:02d}.{self.ext}") for j in range(npiece)]
         if len(jobs) == 1:
             self._atomic_write(*jobs[0])
-        else:
+        elif jobs:
             for f_ in [_writer_pool().submit(self._atomic_write, d_, n_) for d_, n_ in jobs]:
                 f_.result()
         mark = os.path.join(self.path, f"_wave.w{k:06d}.r{self.rank:03d}.ok")
@@ -1032,6 +1052,16 @@ class BatchedLocalExpertOI:
                         jobs.append((wi, pi, loc_ids[c0:c0 + chunk_n]))
             last_job_of_wave = {wi: k for k, (wi, _, _) in enumerate(jobs)}
             state = {}
+            # The predictions are most of a wave's bytes: when a wave's tiles run as consecutive calls of ONE model profile (the
+            # rows of its preds table are then the calls' rows back to back), every call's rows go to the store as a row piece
+            # as soon as the call returns, and the wave's flush is left with the small tables and the marker.
+            jobs_of_wave = {}
+            for k, (wi, pi, _) in enumerate(jobs):
+                jobs_of_wave.setdefault(wi, []).append(k)
+            incremental = {wi: bool(shard_store.path) and predict and len(ks) <= 64 and len({jobs[k][1] for k in ks}) == 1
+                           for wi, ks in jobs_of_wave.items()}
+            piece_futs = {}
+            preds_name = f"preds{table_suffix}"
 
             def open_wave(wi):
                 items = waves[wi]
@@ -1051,7 +1081,13 @@ class BatchedLocalExpertOI:
                 # writer, waves in order, marker last); a flush that fails surfaces when the next one is queued or at the end
                 if pending:
                     pending.pop().result()
-                pending.append(flusher.submit(shard_store.write_wave, tables))
+                pf_ = piece_futs.pop(wi, [])
+
+                def commit(pf_=pf_, tables=tables):
+                    for f_ in pf_:                                     # done by now (one writer, in order): a failed piece fails the wave
+                        f_.result()
+                    shard_store.write_wave(tables, prewritten=(preds_name,) if pf_ else ())
+                pending.append(flusher.submit(commit))
                 self.timings["flush_s"] += time.perf_counter() - tf
                 if len(waves) == 1:
                     single["tables"] = tables                          # the only wave's tables ARE the shard's tables
@@ -1148,6 +1184,11 @@ class BatchedLocalExpertOI:
                             p_off = pk["p_off"]
                             for kk, j in enumerate(loc_ids):
                                 preds[j] = pr[p_off[kk]:p_off[kk + 1]]
+                            if incremental.get(wi):
+                                piece = self._preds_frame(locs[ids], pk["mean"], pr, pcs, ids, np.ones(len(ids), dtype=bool),
+                                                          pcs.counts[ids].astype(np.int64))
+                                piece_futs.setdefault(wi, []).append(
+                                    flusher.submit(shard_store.write_piece, preds_name, jobs_of_wave[wi].index(k), piece))
                             if p_["full_cov"]:
                                 fc = np.asarray(r.f_cov, dtype=np.float64)
                                 for kk, j in enumerate(loc_ids):
@@ -1252,6 +1293,19 @@ class BatchedLocalExpertOI:
         return [self.engine] + self._extra_engines[:max(0, n - 1)]
 
     # ------------------------------------------------------------------------------------------------------
+    def _preds_frame(self, locs, f_bar, pred_cat, rag, items, tile, cnt):
+        """The ``preds`` table of a run of items (``pred_cat``: the predictions of the tiles among them, back to back)."""
+        cc = self.coords_col
+        tot = int(cnt.sum())
+        assert tot == len(pred_cat), (tot, len(pred_cat))
+        raw = rag.take(items[tile]) if tot else np.zeros((0, len(cc)))
+        dim0 = np.arange(tot) - np.repeat(np.concatenate([[0], np.cumsum(cnt)])[:-1], cnt)
+        pr = {"_dim_0": dim0, "f*": pred_cat[:, 0], "f*_var": pred_cat[:, 1], "y_var": pred_cat[:, 2],
+              "f_bar": np.repeat(f_bar, cnt)}
+        for ci, c_ in enumerate(cc):
+            pr[f"pred_loc_{c_}"] = raw[:, ci]
+        return pd.DataFrame(pr, index=_index_for_repeated(cc, locs, cnt))
+
     def _tables(self, ex_ids, locs, kind, n_obs, fixed, pred_cat, pcs, save_params, devices, optimise, config_id,
                 table_suffix, cov_cat=None, cov_tiles=None):
         """Reference-layout tables for a run of items (rows of ``fixed`` align with the items, ``pred_cat`` holds the
@@ -1281,15 +1335,7 @@ class BatchedLocalExpertOI:
             rag, items = pcs                                       # the run's prediction coordinates and these items' positions
             items = np.asarray(items, dtype=np.int64)
             cnt = np.where(tile, rag.counts[items], 0).astype(np.int64)
-            tot = int(cnt.sum())
-            assert tot == len(pred_cat), (tot, len(pred_cat))
-            raw = rag.take(items[tile]) if tot else np.zeros((0, D))
-            dim0 = np.arange(tot) - np.repeat(np.concatenate([[0], np.cumsum(cnt)])[:-1], cnt)
-            pr = {"_dim_0": dim0, "f*": pred_cat[:, 0], "f*_var": pred_cat[:, 1], "y_var": pred_cat[:, 2],
-                  "f_bar": np.repeat(fixed[:, H + 5], cnt)}
-            for ci, c_ in enumerate(cc):
-                pr[f"pred_loc_{c_}"] = raw[:, ci]
-            out["preds"] = pd.DataFrame(pr, index=_index_for_repeated(cc, locs, cnt))
+            out["preds"] = self._preds_frame(locs, fixed[:, H + 5], pred_cat, rag, items, tile, cnt)
             if cov_cat is not None:
                 # 2-D arrays of the prediction dict -> table "preds_2" with _dim_0, _dim_1 (row-major), local_experts.py:735-745
                 c2 = np.where(cov_tiles, cnt, 0)

@@ -196,7 +196,8 @@ def test_store_is_parquet_and_reads_older_pickle_stores(tmp_path):
     files = os.listdir(store)
     assert any(f.startswith("preds.w000001.r000.") and f.endswith(".parquet") for f in files)
     assert not any(f.endswith(".pkl") for f in files)
-    t = pq.read_table(os.path.join(store, "preds.w000001.r000.parquet"))            # readable without this package
+    first = sorted(f for f in files if f.startswith("preds.w000001.r000."))[0]      # the wave's first row piece (one per engine call)
+    t = pq.read_table(os.path.join(store, first))                                  # readable without this package
     assert {"f*", "f*_var", "y_var", "f_bar", "_dim_0", "pred_loc_x"} <= set(t.column_names)
     _assert_same_tables(full, {k: v for k, v in get_results(store).items() if k in full}, ignore=())
     # the same run into a pickle store: identical tables
@@ -298,3 +299,40 @@ def test_explicit_rank_without_group_is_refused_up_front():
     assert eng.calls == []                                                      # refused before any work
     part = BatchedLocalExpertOI(engine=eng, **cfg).run(rank=1, world_size=2, gather=False)
     assert 0 < len(part["run_details"]) < 4
+
+
+def test_prediction_rows_go_out_as_pieces_per_engine_call(tmp_path):
+    """A wave's predictions are written as one row piece per engine call while the wave runs (`ResultStore.write_piece`), the
+    small tables and the marker at its end; the store reads back exactly what the run returned; pieces of a wave that never
+    committed are ignored by readers and removed by the next run; a wave that mixes model profiles is written whole."""
+    cfg = _grid_case(9)
+    store = str(tmp_path / "s")
+    full = BatchedLocalExpertOI(engine=OracleEngine(), **cfg).run(store_path=store, store_every=8, engine_chunk=3)
+    files = sorted(os.listdir(store))
+    assert [f for f in files if f.startswith("preds.w000001.")] == [f"preds.w000001.r000.p{j:02d}.parquet" for j in range(3)]
+    assert [f for f in files if f.startswith("preds.w000002.")] == ["preds.w000002.r000.p00.parquet"]
+    assert "run_details.w000001.r000.parquet" in files and "_wave.w000001.r000.ok" in files
+    _assert_same_tables(full, {k: v for k, v in get_results(store).items() if k in full}, ignore=())
+    # a fault in the SECOND call of the second wave of a fresh run: wave 1 is committed, wave 2's first piece is on disk, unmarked
+    st2 = str(tmp_path / "k")
+    with pytest.raises(RuntimeError):
+        BatchedLocalExpertOI(engine=DyingEngine(die_at_call=5), **cfg).run(store_path=st2, store_every=6, engine_chunk=2)
+    left = sorted(os.listdir(st2))
+    assert "_wave.w000001.r000.ok" in left and "_wave.w000002.r000.ok" not in left
+    assert any(f.startswith("preds.w000002.r000.p") for f in left)                  # the orphan piece
+    assert len(get_results(st2)["run_details"]) == 6                                 # readers see the committed wave only
+    n_committed = len(get_results(st2)["preds"])
+    assert n_committed == int((full["preds"].index.isin(get_results(st2)["run_details"].index)).sum())
+    resumed = BatchedLocalExpertOI(engine=OracleEngine(), **cfg).run(store_path=st2, store_every=6, engine_chunk=2)
+    assert len(resumed["run_details"]) == 3                                          # the run continues after the committed wave
+    _assert_same_tables(full, {k: v for k, v in get_results(st2, expert_order=True).items() if k in full})
+    # two model profiles in one wave (a replacement model below 110 observations): the wave's preds table is written whole
+    cfg2 = _grid_case(9)
+    cfg2["model_config"]["replacement_threshold"] = 110
+    cfg2["model_config"]["replacement_init_params"] = {"kernel": "RBF"}
+    st3 = str(tmp_path / "m")
+    oi = BatchedLocalExpertOI(engine=OracleEngine(), **cfg2)
+    both = oi.run(store_path=st3, store_every=9, engine_chunk=4)
+    assert len(set(both["run_details"]["num_obs"] < 110)) == 2                       # both profiles present in the wave
+    assert "preds.w000001.r000.parquet" in os.listdir(st3)
+    _assert_same_tables(both, {k: v for k, v in get_results(st3).items() if k in both}, ignore=())
