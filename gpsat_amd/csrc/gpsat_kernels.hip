@@ -1388,8 +1388,17 @@ __device__ __forceinline__ void kinv_kloop(const float* __restrict__ ws, int NB,
         fA[m] = ldg_half(ws, a0 * NB + a0, m, lane);
         if (!DIAG) { fB0[m] = ldg_half(ws, a0 * NB + b0, m, lane); fB1[m] = ldg_half(ws, a0 * NB + b0 + 1, m, lane); }
     }
+    // 8-wave build: three operand sets in rotation, two half steps of loads in flight (configs[2] +0.4 %); in the 4-wave build
+    // the third set spills (configs[1] -0.9 %) and the CU's other workgroup covers the wait anyway: two sets in ping-pong
+#ifdef GPSAT_W8
+    const int n = 2 * (NB - a1);
+    auto load_i = [&](KinvOps& S, int i) { const int ii = max(min(i, n - 1), 0); kinv_load<DIAG>(S, ws, NB, min(a1 + (ii >> 1), NB - 1), ii & 1, a0, b0, lane); };
+    KinvOps S0, S1, S2;
+    if (n > 0) { load_i(S0, 0); load_i(S1, 1); }
+#else
     KinvOps S0, S1;
     if (a1 < NB) kinv_load<DIAG>(S0, ws, NB, a1, 0, a0, b0, lane);
+#endif
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         HalfPl A = split_half(fA[m]);
@@ -1401,12 +1410,26 @@ __device__ __forceinline__ void kinv_kloop(const float* __restrict__ ws, int NB,
             mma_half(acc[1], A, B1);
         }
     }
+#ifdef GPSAT_W8
+    int i = 0;
+    for (; i + 3 <= n; i += 3) {
+        load_i(S2, i + 2);
+        kinv_comp<DIAG>(acc, S0);
+        load_i(S0, i + 3);
+        kinv_comp<DIAG>(acc, S1);
+        load_i(S1, i + 4);
+        kinv_comp<DIAG>(acc, S2);
+    }
+    if (i < n) { kinv_comp<DIAG>(acc, S0); ++i; }
+    if (i < n) kinv_comp<DIAG>(acc, S1);
+#else
     for (int cc = a1; cc < NB; ++cc) {
         kinv_load<DIAG>(S1, ws, NB, cc, 1, a0, b0, lane);
         kinv_comp<DIAG>(acc, S0);
         kinv_load<DIAG>(S0, ws, NB, min(cc + 1, NB - 1), 0, a0, b0, lane);     // past the end: the last row again, unused
         kinv_comp<DIAG>(acc, S1);
     }
+#endif
 }
 
 // one K^-1 group (a0 = 2 ia, b0 = 2 ib): k-loop, contraction, per-lane partial sums -> gpart[g]
