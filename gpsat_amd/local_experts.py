@@ -484,12 +484,14 @@ class ResultStore:
         assert 0 <= j < 100
         self._atomic_write(df, f"{name}.w{self._wave_number():06d}.r{self.rank:03d}.p{j:02d}.{self.ext}")
 
-    def write_wave(self, tables: Dict[str, pd.DataFrame], prewritten=()):
-        """One committed part per non-empty table (``prewritten``: tables whose rows went out as ``write_piece`` pieces)."""
+    def write_wave(self, tables: Dict[str, pd.DataFrame], prewritten=None):
+        """One committed part per non-empty table (``prewritten``: {table: rows} of the tables whose rows went out as
+        ``write_piece`` pieces -- they are committed by the same marker)."""
         if not self.path:
             return
+        prewritten = dict(prewritten or {})
         tables = {k: v for k, v in tables.items() if v is not None and len(v)}
-        if not tables:
+        if not tables and not prewritten:
             self._open_k = None
             return
         k = self._wave_number()
@@ -512,7 +514,9 @@ class ResultStore:
                 f_.result()
         mark = os.path.join(self.path, f"_wave.w{k:06d}.r{self.rank:03d}.ok")
         with open(mark + ".tmp", "w") as f:
-            f.write(json.dumps({"tables": sorted(tables), "rows": {n: int(len(d)) for n, d in tables.items()}}))
+            rows = {n: int(len(d)) for n, d in tables.items()}
+            rows.update({n: int(r) for n, r in prewritten.items()})
+            f.write(json.dumps({"tables": sorted(rows), "rows": rows}))
         os.replace(mark + ".tmp", mark)
 
     def append(self, table, df: pd.DataFrame):
@@ -973,12 +977,12 @@ class BatchedLocalExpertOI:
         self.timings.update(engine_s=0.0, engine_call_s=0.0, kernel_s=0.0, tables_s=0.0, flush_s=0.0)
         self.timings["calls"] = []          # per engine call: (job, tiles, start, end, kernel seconds), times from the start of run()
 
-        def tables_for(items, fixed, pred_cat, cov_cat=None):
+        def tables_for(items, fixed, pred_cat, cov_cat=None, with_preds=True):
             return self._tables(ex[items], locs[items], kind[items], n_obs[items], fixed, pred_cat,
                                 (pcs, items) if predict else None, save_params[items],
                                 [tmpl[p]["device"] for p in prof_id[items]], optimise, config_id, table_suffix,
                                 cov_cat=cov_cat, cov_tiles=(kind[items] == 2) & np.array([pinfo[p]["full_cov"] for p in prof_id[items]], dtype=bool)
-                                if want_cov else None)
+                                if want_cov else None, with_preds=with_preds)
 
         # ---------------- pass 2: waves of one shard ----------------
         def pack_job(ids, pi):
@@ -1074,22 +1078,32 @@ class BatchedLocalExpertOI:
                 tt = time.perf_counter()
                 pred_cat = np.concatenate(preds) if len(preds) else np.zeros((0, 3))
                 cov_cat = (np.concatenate(covs) if len(covs) else np.zeros((0, 2))) if want_cov else None
-                tables = tables_for(items, fixed, pred_cat, cov_cat)
+                pf_ = piece_futs.pop(wi, [])
+                # the predictions went out as pieces: the wave's flush needs the small tables only, and the wave's preds frame
+                # is built (after the flush is queued) only where it is returned -- the only wave of a run
+                lazy = bool(pf_) and not want_cov
+                tables = tables_for(items, fixed, pred_cat, cov_cat, with_preds=not lazy)
                 self.timings["tables_s"] += time.perf_counter() - tt
                 tf = time.perf_counter()
                 # commit: these experts are done.  The parts are written by a helper thread while the next wave runs (one
                 # writer, waves in order, marker last); a flush that fails surfaces when the next one is queued or at the end
                 if pending:
                     pending.pop().result()
-                pf_ = piece_futs.pop(wi, [])
 
-                def commit(pf_=pf_, tables=tables):
+                def commit(pf_=pf_, tables=dict(tables), n_pred_rows=len(pred_cat)):
                     for f_ in pf_:                                     # done by now (one writer, in order): a failed piece fails the wave
                         f_.result()
-                    shard_store.write_wave(tables, prewritten=(preds_name,) if pf_ else ())
+                    shard_store.write_wave(tables, prewritten={preds_name: n_pred_rows} if pf_ else {})
                 pending.append(flusher.submit(commit))
                 self.timings["flush_s"] += time.perf_counter() - tf
                 if len(waves) == 1:
+                    if lazy:
+                        tt = time.perf_counter()
+                        tile_ = kind[items] == 2
+                        cnt_ = np.where(tile_, pcs.counts[items], 0).astype(np.int64)
+                        tables[preds_name] = self._preds_frame(locs[items], fixed[:, H + 5], pred_cat, pcs,
+                                                               np.asarray(items, dtype=np.int64), tile_, cnt_)
+                        self.timings["tables_s"] += time.perf_counter() - tt
                     single["tables"] = tables                          # the only wave's tables ARE the shard's tables
                 fixed_rows.append(fixed)
                 pred_rows.append(pred_cat)
@@ -1307,7 +1321,7 @@ class BatchedLocalExpertOI:
         return pd.DataFrame(pr, index=_index_for_repeated(cc, locs, cnt))
 
     def _tables(self, ex_ids, locs, kind, n_obs, fixed, pred_cat, pcs, save_params, devices, optimise, config_id,
-                table_suffix, cov_cat=None, cov_tiles=None):
+                table_suffix, cov_cat=None, cov_tiles=None, with_preds=True):
         """Reference-layout tables for a run of items (rows of ``fixed`` align with the items, ``pred_cat`` holds the
         predictions of the tiles among them back to back).  Pure array assembly (GPSat/local_experts.py:691-747)."""
         cc = self.coords_col
@@ -1331,7 +1345,9 @@ class BatchedLocalExpertOI:
             vals = fixed[sp, start:start + width].reshape(-1)
             out[pn] = pd.DataFrame({"_dim_0": np.tile(np.arange(width), int(sp.sum())), pn: vals},
                                    index=_index_for_repeated(cc, locs[sp], np.full(int(sp.sum()), width)))
-        if pcs is not None:
+        if pcs is not None and not with_preds:
+            pass                                                   # the caller has written the rows as pieces and builds the frame itself
+        elif pcs is not None:
             rag, items = pcs                                       # the run's prediction coordinates and these items' positions
             items = np.asarray(items, dtype=np.int64)
             cnt = np.where(tile, rag.counts[items], 0).astype(np.int64)
