@@ -223,3 +223,21 @@ def test_replacement_model_for_small_tiles(tmp_path):
     o = go.OracleGPR(d[["x"]].values, d[["y"]].values, kernel="Matern32", noise_variance=noise_std ** 2)
     o.set_parameters(lengthscales=[0.07], kernel_variance=float(tabs["kernel_variance"]["kernel_variance"].loc[0.3]))
     assert o.get_objective_function_value() == pytest.approx(rd["objective_value"].loc[0.3], abs=1e-4)   # fp32-packed inputs
+
+
+def test_ragged_rows_reads_like_a_list_of_arrays():
+    """`RaggedRows` (the prediction coordinates of all experts in one array): indexing, iteration and `take` of consecutive,
+    scattered, repeated and empty selections equal the list-of-arrays form they replaced."""
+    from gpsat_amd.local_experts import RaggedRows
+    rng = np.random.default_rng(0)
+    counts = np.array([3, 0, 5, 1, 0, 0, 4, 2])
+    rows = [rng.normal(size=(c, 3)) for c in counts]
+    off = np.concatenate([[0], np.cumsum(counts)])
+    rr = RaggedRows(np.concatenate(rows), off)
+    assert len(rr) == len(rows) and (rr.counts == counts).all()
+    for a, b in zip(rr, rows):
+        assert np.array_equal(a, b)
+    for items in ([0, 1, 2, 3], [2], [7, 0, 2], [1, 4, 5], [], [3, 3, 6], list(range(8))):
+        want = np.concatenate([rows[i] for i in items]) if len(items) else np.zeros((0, 3))
+        got = rr.take(np.asarray(items, dtype=np.int64))
+        assert got.shape == want.shape and np.array_equal(got, want), items
